@@ -1,0 +1,97 @@
+/*
+ * dgnn_spmm.h -- C ABI of libdgnn_spmm.so, the MI355X (gfx950) replacement for
+ * dist-gnn's native SpMM operator.
+ *
+ * Every entry point takes plain device pointers and sizes, an explicit HIP
+ * stream (passed as void* so the header needs no HIP include; NULL = the
+ * null stream), and returns an int status: 0 = ok, nonzero = DGNN_E_* below.
+ * After a nonzero return dgnn_last_error() gives a thread-local message.
+ * Nothing here synchronises the host with the device and nothing allocates
+ * device memory: all launches are asynchronous on `stream`.
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   light_dist_gnn/spmm_cpp/spmm.cpp:17-33          spmm_cusparse (cusparseSpMM, COO_ALG4)
+ *   light_dist_gnn/spmm_cpp/spmm_original.cpp:114-193 spmm_cusparse (coo2csr + csrmm2)
+ *   1D_CAGNET/sparse-extension/sparse_coo_tensor.cpp:115-196 spmm_gpu (alpha=beta=1)
+ *   light_dist_gnn/models/gcn.py:9-13               the `spmm` marshalling lambda
+ */
+#ifndef DGNN_SPMM_H
+#define DGNN_SPMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGNN_OK            0
+#define DGNN_E_BADARG      1  /* null pointer, negative size, misaligned or aliasing operands */
+#define DGNN_E_HIP         2  /* a HIP runtime call or a kernel launch failed                 */
+#define DGNN_E_NODEVICE    3  /* no gfx950 device visible to this process                     */
+
+/* Library version: major*10000 + minor*100 + patch. */
+int dgnn_version(void);
+
+/* Message for the last nonzero status returned on the calling thread ("" if none). */
+const char* dgnn_last_error(void);
+
+/*
+ * Sorted COO row indices -> CSR row pointer.
+ *   row[nnz]     int32, non-decreasing, each in [0, n)   (what coalesce() guarantees,
+ *                light_dist_gnn/coo_graph/graph_utils.py:48)
+ *   rowptr[n+1]  int32 out: rowptr[i] = number of k with row[k] < i
+ * Replaces cusparseXcoo2csr (spmm_original.cpp:141-146, sparse_coo_tensor.cpp:142-147),
+ * which the reference re-runs (with a cudaMalloc) on every SpMM call.
+ */
+int dgnn_coo2csr_i32(const int32_t* row, int64_t nnz, int32_t n,
+                     int32_t* rowptr, void* stream);
+
+/*
+ * C[n x F] = alpha * A[n x m] * B[m x F] + beta * C        (fp32, row-major, in place)
+ *   A in CSR: rowptr[n+1], col[nnz], val[nnz]; columns of a row in ascending order
+ *   B: ldb floats between rows (ldb >= F); C: ldc floats between rows (ldc >= F)
+ *   beta == 0 never reads C (C may hold NaN/uninitialised memory).
+ * B and C must not overlap. Each output element is accumulated in ascending
+ * nonzero order by one lane, with fused multiply-adds: results are
+ * run-to-run identical (no atomics).
+ * Replaces cusparseSpMM / cusparseScsrmm2 (spmm.cpp:26-28, spmm_original.cpp:168-184).
+ */
+int dgnn_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                      int32_t n, int32_t m, int64_t nnz,
+                      const float* B, int64_t ldb,
+                      float* C, int64_t ldc, int32_t F,
+                      float alpha, float beta, void* stream);
+
+/*
+ * Same operation on row-sorted COO input, the exact operand list of
+ * spmm_cusparse (spmm.cpp:16-17): row[nnz], col[nnz], val[nnz].
+ * `rowptr_ws` is caller-provided workspace of (n+1) int32 that receives the CSR
+ * row pointer (coo2csr + csr spmm on the same stream).
+ */
+int dgnn_spmm_coo_f32(const int32_t* row, const int32_t* col, const float* val,
+                      int32_t n, int32_t m, int64_t nnz,
+                      int32_t* rowptr_ws,
+                      const float* B, int64_t ldb,
+                      float* C, int64_t ldc, int32_t F,
+                      float alpha, float beta, void* stream);
+
+/*
+ * int64 COO indices (what torch.sparse_coo_tensor.indices() holds) -> int32.
+ * Replaces the two `A.indices()[k].int()` copies the reference makes on every
+ * call (light_dist_gnn/models/gcn.py:11). Values must fit int32; checked on the
+ * host by the caller (sizes), not on the device.
+ */
+int dgnn_idx_i64_to_i32(const int64_t* src, int64_t count, int32_t* dst, void* stream);
+
+/*
+ * Kernel-variant selector for benchmarking and A/B tests (0 = automatic choice).
+ * Not part of the reference interface; affects only speed, never results
+ * beyond fp32 summation order documented per variant in DESIGN.md.
+ */
+int dgnn_set_variant(int variant);
+int dgnn_get_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGNN_SPMM_H */

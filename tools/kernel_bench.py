@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B bench of the SpMM on a dataset-shaped synthetic graph (GPU only).
+
+python tools/kernel_bench.py --shape reddit --F 602,256,41 [--variants 0,1] [--scale 1.0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'dist-gnn_amd'))
+import spmm_cpp  # noqa: E402
+from coo_graph import synthetic, graph_utils  # noqa: E402
+
+
+def build_graph(shape, scale, seed, dev):
+    n, e, f, c, _ = synthetic.SHAPES[shape]
+    n, e = int(n * scale), int(e * scale * scale) if scale < 1 else e
+    t0 = time.time()
+    d = synthetic.make_dataset(shape, seed=seed, device=dev, num_nodes=n, num_edges=e, with_features=False)
+    adj = graph_utils.sym_normalization(d['edge_index'], n)
+    del d
+    A = spmm_cpp.CsrBlock.from_coo(adj)
+    torch.cuda.synchronize()
+    print(f'# graph {shape} n={n} nnz={A.nnz} built in {time.time()-t0:.1f}s', flush=True)
+    return A, adj
+
+
+def time_call(fn, iters, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--shape', default='reddit')
+    ap.add_argument('--scale', type=float, default=1.0)
+    ap.add_argument('--F', default='602,256,41')
+    ap.add_argument('--variants', default='0')
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--beta', type=float, default=1.0)
+    ap.add_argument('--torch-ref', action='store_true')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    A, adj = build_graph(args.shape, args.scale, 0, dev)
+    deg = (A.rowptr[1:] - A.rowptr[:-1]).float()
+    print(f'# degree: mean {deg.mean().item():.1f} max {int(deg.max().item())} p99 {deg.quantile(0.99).item():.0f}', flush=True)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    for F in [int(x) for x in args.F.split(',')]:
+        B = torch.rand(A.m, F, device=dev, generator=g)
+        C = torch.zeros(A.n, F, device=dev)
+        alg_bytes = 8 * A.nnz + 4 * (A.n + 1) + 4 * A.m * F + 4 * A.n * F * (2 if args.beta != 0 else 1)
+        ref = None
+        if args.torch_ref:
+            ref = torch.sparse.mm(adj, B)
+            med, _ = time_call(lambda: torch.sparse.mm(adj, B), 3, 1)
+            print(f'F={F:4d} torch.sparse.mm(COO) {med:8.3f} ms  {A.nnz/med/1e6:7.2f} GEdges/s', flush=True)
+        for v in [int(x) for x in args.variants.split(',')]:
+            spmm_cpp.set_variant(v)
+            C.zero_()
+            spmm_cpp.spmm_csr(A, B, C, 1.0, 0.0)
+            err = ''
+            if ref is not None:
+                err = f' relerr {((C - ref).abs().max() / ref.abs().max()).item():.2e}'
+            med, best = time_call(lambda: spmm_cpp.spmm_csr(A, B, C, 1.0, args.beta), args.iters, args.warmup)
+            print(f'F={F:4d} variant {v}: {med:8.3f} ms (best {best:.3f})  {A.nnz/med/1e6:7.2f} GEdges/s  '
+                  f'alg {alg_bytes/med/1e6:7.1f} GB/s = {alg_bytes/med/1e6/8000:.3f} of 8 TB/s  '
+                  f'gather {4*F*A.nnz/med/1e9:6.2f} TB/s{err}', flush=True)
+        del B, C
+
+
+if __name__ == '__main__':
+    main()

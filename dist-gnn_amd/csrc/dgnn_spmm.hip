@@ -2,19 +2,25 @@
 // include/dgnn_spmm.h. Replaces dist-gnn's cuSPARSE wrapper
 // (reference: light_dist_gnn/spmm_cpp/spmm.cpp:17-33, spmm_original.cpp:114-193).
 //
-// The SpMM is a gather: every nonzero (i, j, a) pulls the F floats of B[j, :] through the
-// cache hierarchy and fuses them into the accumulators of C[i, :]. There is no MFMA here;
-// the limits are the vector-memory (TA/L1 -> L2 -> Infinity Cache -> HBM) gather rate and,
-// for the algorithmic byte count, HBM. Layout and mapping:
+// The SpMM  C = alpha*A*B + beta*C  is a gather: every nonzero (i, j, a) pulls the F floats of
+// B[j, :] through the cache hierarchy and fuses them into the accumulators of C[i, :]. There is
+// no MFMA here. What bounds it on MI355X is the vector-memory gather rate (L1/TA -> per-XCD L2
+// -> Infinity Cache -> HBM); the kernels below are organised around keeping gathers L2-resident
+// and many of them in flight. Two kernel families:
 //
-//   * CSR (int32 rowptr/col, fp32 val) -- (col, val) of a row are read as coalesced
-//     64-entry (or L-entry) segments, one entry per lane, and handed lane-to-lane with
-//     v_readlane (wave-uniform column -> scalar row base) or ds_bpermute (sub-wave groups).
-//   * A "group" of L lanes (L = 64, 32, 16, 8) owns one output row; lane li owns VW
-//     consecutive floats (VW = 4/2/1 -> global_load_dwordx4/x2/x1) of each of NPASS
-//     feature passes, so every output element has exactly one accumulator that sees the
-//     row's nonzeros in ascending order: bit-reproducible, no atomics.
-//   * Feature chunks wider than one group pass go to blockIdx.y.
+//   spmm_rows_kernel   general operands (any alignment / leading dimension). One group of L
+//                      lanes owns one output row; strictly ascending accumulation.
+//   spmm_stage_kernel  the fast path: needs a work plan (dgnn_plan) and a B whose rows are
+//                      16-byte aligned (ldb % 4 == 0). Feature chunks of 64 floats, XCD-aware
+//                      chunk-major work order, column-block stages, long rows cut in pieces.
+//
+// In both, a (col, val) run of a row is read as one coalesced L-entry segment (one entry per
+// lane) and handed lane-to-lane (v_readlane when L == 64, ds_bpermute otherwise); lane li
+// owns VW consecutive floats of the feature chunk; every output element has exactly one
+// accumulator that starts at beta*C and sees its nonzeros in ascending order with fused
+// multiply-adds -- the same chain as ATen's CPU sparse addmm (oracle/spmm_ref.c), so results
+// are bit-identical to the oracle except for rows the plan cuts into pieces (fixed-order
+// piece sums: deterministic, within fp32 rounding of the chain). No atomics anywhere.
 //
 // 64-wide wavefronts are assumed throughout (gfx950 only).
 
@@ -64,7 +70,7 @@ __device__ __forceinline__ void st_vec(float* p, const float (&d)[VW]) {
   *reinterpret_cast<typename Vec<VW>::T*>(p) = t;
 }
 
-// Hand one (col, val) entry from lane `src` of the group to every lane of the group.
+// Hand entry j of the group's staged (col, val) segment to every lane of the group.
 template <int L>
 __device__ __forceinline__ void bcast_entry(int cv, float vv, int g, int j, int& c, float& v) {
   if constexpr (L == 64) {
@@ -78,7 +84,8 @@ __device__ __forceinline__ void bcast_entry(int cv, float vv, int g, int j, int&
 }
 
 // ---------------------------------------------------------------------------------------
-// Row-per-group CSR SpMM.  grid.x = ceil(n / (4 waves * G rows)), grid.y = feature chunks.
+// General path: row-per-group CSR SpMM.
+//   grid.x = ceil(n / (4 waves * G rows)), grid.y = feature chunks of L*VW*NPASS floats.
 // ---------------------------------------------------------------------------------------
 template <int VW, int L, int NPASS>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(
@@ -102,8 +109,6 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) fok[p] = (fbase + p * L * VW) < F;
 
-  // acc starts from beta*C and every nonzero adds fma(alpha*a, b, acc) in ascending order:
-  // the same chain as ATen's CPU sparse addmm (oracle/spmm_ref.c), so results agree bit for bit.
   float acc[NPASS][VW];
   float* const cr = C + row * ldc + fbase;
 #pragma unroll
@@ -174,8 +179,138 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// coo2csr: thread k closes every row boundary between row[k-1] and row[k].
+// Fast path: plan-driven, staged SpMM.
+//
+// A plan (dgnn_plan, include/dgnn_spmm.h) cuts the column space into `nstage` blocks. A
+// *segment* is the run of one row's nonzeros inside one column block (contiguous, because CSR
+// columns ascend). Stages are separate launches on one stream, each accumulating into C, so an
+// output element still sees its nonzeros in ascending column order across stages. Inside a
+// stage the segments are listed longest first (LPT), and a segment longer than the plan's
+// piece length is cut into pieces whose sums go to `partial` and are added to C in piece order
+// by merge_kernel right after the stage.
+//
+// One group of L lanes takes one segment and one 4*L-float feature chunk; B rows are read as
+// float4 (global_load_dwordx4: B must have ldb % 4 == 0 and a 16-byte-aligned base, padding
+// columns zero or anything finite -- they are never stored), C as VWC-float vectors.
+//
+// XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
+// XCD group; each XCD has a private 4 MiB L2). The work index is laid out chunk-major and XCD
+// group x takes the x-th contiguous eighth of it, so at any moment the workgroups resident on
+// one XCD gather from one 256-byte feature chunk of one column block of B: the L2 working set
+// is (columns per block) x 256 B instead of whole B rows.
 // ---------------------------------------------------------------------------------------
+template <int L, int U, int VWC>
+__global__ __launch_bounds__(256) void spmm_stage_kernel(
+    const int4* __restrict__ seg, int32_t nseg, uint32_t nsegblocks,
+    const int32_t* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+    float* __restrict__ P, int64_t ldp, int32_t F, float alpha) {
+  constexpr int G = 64 / L;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L;
+  const int li = lane % L;
+
+  const uint32_t nb = gridDim.x, b = blockIdx.x;
+  const uint32_t q = nb >> 3, r = nb & 7, xcd = b & 7;
+  const uint32_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const uint32_t chunk = w / nsegblocks;
+  const uint32_t sb = w - chunk * nsegblocks;
+
+  const int64_t sidx = ((int64_t)sb * 4 + wave) * G + g;
+  const int fbase = (chunk * L + li) * 4;
+  const bool live = sidx < nseg;
+  int4 s = make_int4(0, 0, 0, -1);             // {row, k0, k1, out}: out < 0 -> accumulate into C[row]
+  if (live) s = seg[sidx];
+  const int kb = s.y, ke = s.z;
+  const bool fb = fbase < ldb;                  // lane has a float4 of B to gather
+  const bool direct = s.w < 0;
+
+  float* const dst = direct ? (C + (int64_t)s.x * ldc + fbase) : (P + (int64_t)s.w * ldp + fbase);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live && direct) {                         // pieces start from 0, direct segments from C
+    if constexpr (VWC == 4) { if (fbase < F) ld_vec<4>(dst, acc); }
+    if constexpr (VWC == 2) {
+      float t[2];
+      if (fbase < F) { ld_vec<2>(dst, t); acc[0] = t[0]; acc[1] = t[1]; }
+      if (fbase + 2 < F) { ld_vec<2>(dst + 2, t); acc[2] = t[0]; acc[3] = t[1]; }
+    }
+    if constexpr (VWC == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (fbase + e < F) acc[e] = dst[e];
+    }
+  }
+
+  const float* Bf = B + fbase;
+  for (int k0 = kb; k0 < ke; k0 += L) {
+    const int kk = k0 + li;
+    int cv = 0; float vv = 0.f;
+    if (kk < ke) { cv = col[kk]; vv = alpha * val[kk]; }
+    const int cnt = min(L, ke - k0);
+    int j = 0;
+    for (; j + U <= cnt; j += U) {
+      int c[U]; float v[U];
+      float bb[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) bcast_entry<L>(cv, vv, g, j + u, c[u], v[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (fb) ld_vec<4>(Bf + (int64_t)c[u] * ldb, bb[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (fb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[u], bb[u][e], acc[e]);
+        }
+    }
+    for (; j < cnt; ++j) {
+      int c; float v;
+      bcast_entry<L>(cv, vv, g, j, c, v);
+      if (fb) {
+        float bb[4];
+        ld_vec<4>(Bf + (int64_t)c * ldb, bb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, bb[e], acc[e]);
+      }
+    }
+  }
+
+  if (live) {
+    if (!direct) {                              // partial rows are ours: ldp % 4 == 0, 16-B aligned
+      if (fbase < ldp) st_vec<4>(dst, acc);
+    } else {
+      if constexpr (VWC == 4) { if (fbase < F) st_vec<4>(dst, acc); }
+      if constexpr (VWC == 2) {
+        float t[2];
+        if (fbase < F) { t[0] = acc[0]; t[1] = acc[1]; st_vec<2>(dst, t); }
+        if (fbase + 2 < F) { t[0] = acc[2]; t[1] = acc[3]; st_vec<2>(dst + 2, t); }
+      }
+      if constexpr (VWC == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (fbase + e < F) dst[e] = acc[e];
+      }
+    }
+  }
+}
+
+// C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order); one block per cut segment.
+__global__ __launch_bounds__(256) void merge_kernel(
+    const int4* __restrict__ cut, const float* __restrict__ P, int64_t ldp,
+    float* __restrict__ C, int64_t ldc, int32_t F) {
+  const int4 c4 = cut[blockIdx.x];             // {row, pbase, count, -}
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float* c = C + (int64_t)c4.x * ldc + f;
+    float acc = *c;
+    const float* p = P + (int64_t)c4.y * ldp + f;
+    for (int s = 0; s < c4.z; ++s) acc += p[(int64_t)s * ldp];
+    *c = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Index / layout helpers.
+// ---------------------------------------------------------------------------------------
+// coo2csr: thread k closes every row boundary between row[k-1] and row[k].
 __global__ __launch_bounds__(256) void coo2csr_kernel(const int32_t* __restrict__ row, int64_t nnz,
                                                       int32_t n, int32_t* __restrict__ rowptr) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -193,7 +328,7 @@ __global__ __launch_bounds__(256) void idx_narrow_kernel(const int64_t* __restri
     dst[k] = (int32_t)src[k];
 }
 
-// beta-only path for an empty A (nnz == 0): C = beta * C.
+// C = beta * C (beta == 0 writes zeros without reading).
 __global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ C, int64_t ldc, int32_t n,
                                                          int32_t F, float beta) {
   const int64_t total = (int64_t)n * F;
@@ -202,6 +337,29 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ C, 
     float* p = C + (t / F) * ldc + (t % F);
     *p = (beta == 0.f) ? 0.f : beta * *p;
   }
+}
+
+// dst[r, 0:F] = src[r, 0:F]; dst[r, F:ldd] = 0. One float4 of dst per thread (ldd % 4 == 0).
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                       float* __restrict__ dst, int64_t ldd,
+                                                       int32_t n, int32_t F) {
+  const int64_t q4 = ldd / 4;
+  const int64_t total = (int64_t)n * q4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / q4;
+    const int f = (int)(t - r * q4) * 4;
+    const float* s = src + r * lds + f;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (f + e < F) ? s[e] : 0.f;
+    st_vec<4>(dst + r * ldd + f, o);
+  }
+}
+
+unsigned capped_blocks(int64_t work, unsigned cap) {
+  const int64_t b = (work + 255) / 256;
+  return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 struct Args {
@@ -251,11 +409,36 @@ int dispatch_rows(const Args& a) {
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+bool overlap(const float* B, int64_t rows_b, int64_t ldb, const float* C, int64_t rows_c, int64_t ldc, int F) {
+  if (rows_b <= 0 || rows_c <= 0) return false;
+  const uintptr_t b0 = (uintptr_t)B, b1 = b0 + ((uint64_t)(rows_b - 1) * ldb + F) * 4;
+  const uintptr_t c0 = (uintptr_t)C, c1 = c0 + ((uint64_t)(rows_c - 1) * ldc + F) * 4;
+  return b0 < c1 && c0 < b1;
+}
+
+template <int L, int U>
+int launch_stage(int vwc, const int4* seg, int32_t nseg, const int32_t* col, const float* val,
+                 const float* B, int64_t ldb, float* C, int64_t ldc, float* P, int64_t ldp,
+                 int32_t F, float alpha, hipStream_t s) {
+  constexpr int G = 64 / L;
+  const int64_t nsegblocks = ((int64_t)nseg + 4 * G - 1) / (4 * G);
+  const int64_t nchunks = (ldb / 4 + L - 1) / L;
+  const int64_t nb = nsegblocks * nchunks;
+  if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "stage grid out of range%s (%lld)", "", nb);
+#define DGNN_STAGE(VWC)                                                                              \
+  hipLaunchKernelGGL((spmm_stage_kernel<L, U, VWC>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
+                     (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha)
+  if (vwc == 4) DGNN_STAGE(4); else if (vwc == 2) DGNN_STAGE(2); else DGNN_STAGE(1);
+#undef DGNN_STAGE
+  DGNN_HIP(hipGetLastError());
+  return DGNN_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int dgnn_version(void) { return 100; }
+int dgnn_version(void) { return 200; }
 
 const char* dgnn_last_error(void) { return g_err; }
 
@@ -265,9 +448,8 @@ int dgnn_get_variant(void) { return g_variant; }
 int dgnn_coo2csr_i32(const int32_t* row, int64_t nnz, int32_t n, int32_t* rowptr, void* stream) {
   if (n < 0 || nnz < 0 || nnz > 0x7fffffffLL) return fail(DGNN_E_BADARG, "coo2csr: bad sizes%s (nnz=%lld)", "", nnz);
   if (!rowptr || (nnz > 0 && !row)) return fail(DGNN_E_BADARG, "coo2csr: null pointer%s", "");
-  const int64_t work = nnz + 1;
-  const unsigned blocks = (unsigned)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
-  hipLaunchKernelGGL(coo2csr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, row, nnz, n, rowptr);
+  hipLaunchKernelGGL(coo2csr_kernel, dim3(capped_blocks(nnz + 1, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     row, nnz, n, rowptr);
   DGNN_HIP(hipGetLastError());
   return DGNN_OK;
 }
@@ -276,8 +458,21 @@ int dgnn_idx_i64_to_i32(const int64_t* src, int64_t count, int32_t* dst, void* s
   if (count < 0) return fail(DGNN_E_BADARG, "idx_i64_to_i32: negative count%s", "");
   if (count == 0) return DGNN_OK;
   if (!src || !dst) return fail(DGNN_E_BADARG, "idx_i64_to_i32: null pointer%s", "");
-  const unsigned blocks = (unsigned)((count + 255) / 256 > 8192 ? 8192 : (count + 255) / 256);
-  hipLaunchKernelGGL(idx_narrow_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, count, dst);
+  hipLaunchKernelGGL(idx_narrow_kernel, dim3(capped_blocks(count, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     src, count, dst);
+  DGNN_HIP(hipGetLastError());
+  return DGNN_OK;
+}
+
+int dgnn_pad_rows_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t n, int32_t F, void* stream) {
+  if (n < 0 || F < 0) return fail(DGNN_E_BADARG, "pad_rows: negative size%s", "");
+  if (n == 0 || ldd == 0) return DGNN_OK;
+  if (!src || !dst) return fail(DGNN_E_BADARG, "pad_rows: null pointer%s", "");
+  if (lds < F || ldd < F || ldd % 4 != 0 || !aligned(dst, 16))
+    return fail(DGNN_E_BADARG, "pad_rows: need lds >= F, ldd >= F, ldd %% 4 == 0, dst 16-byte aligned%s", "");
+  if (overlap(src, n, lds, dst, n, ldd, F)) return fail(DGNN_E_BADARG, "pad_rows: src and dst overlap%s", "");
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(capped_blocks((int64_t)n * (ldd / 4), 16384)), dim3(256), 0,
+                     (hipStream_t)stream, src, lds, dst, ldd, n, F);
   DGNN_HIP(hipGetLastError());
   return DGNN_OK;
 }
@@ -294,19 +489,13 @@ int dgnn_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
   hipStream_t s = (hipStream_t)stream;
   if (nnz == 0) {
     if (beta == 1.f) return DGNN_OK;
-    const int64_t total = (int64_t)n * F;
-    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, s, C, ldc, n, F, beta);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(capped_blocks((int64_t)n * F, 8192)), dim3(256), 0, s, C, ldc, n, F, beta);
     DGNN_HIP(hipGetLastError());
     return DGNN_OK;
   }
   if (!col || !val || !B) return fail(DGNN_E_BADARG, "spmm_csr: null col/val/B%s", "");
   if (ldb < F) return fail(DGNN_E_BADARG, "spmm_csr: ldb < F%s (ldb=%lld)", "", ldb);
-  {  // B and C must not overlap (the kernel reads B rows while other waves write C rows)
-    const uintptr_t b0 = (uintptr_t)B, b1 = b0 + ((uint64_t)(m > 0 ? m - 1 : 0) * ldb + F) * 4;
-    const uintptr_t c0 = (uintptr_t)C, c1 = c0 + ((uint64_t)(n - 1) * ldc + F) * 4;
-    if (m > 0 && b0 < c1 && c0 < b1) return fail(DGNN_E_BADARG, "spmm_csr: B and C overlap%s", "");
-  }
+  if (overlap(B, m, ldb, C, n, ldc, F)) return fail(DGNN_E_BADARG, "spmm_csr: B and C overlap%s", "");
   Args a{rowptr, col, val, n, B, ldb, C, ldc, F, alpha, beta, s};
   if (F % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned(B, 16) && aligned(C, 16)) return dispatch_rows<4>(a);
   if (F % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 && aligned(B, 8) && aligned(C, 8)) return dispatch_rows<2>(a);
@@ -322,6 +511,50 @@ int dgnn_spmm_coo_f32(const int32_t* row, const int32_t* col, const float* val,
   int rc = dgnn_coo2csr_i32(row, nnz, n, rowptr_ws, stream);
   if (rc != DGNN_OK) return rc;
   return dgnn_spmm_csr_f32(rowptr_ws, col, val, n, m, nnz, B, ldb, C, ldc, F, alpha, beta, stream);
+}
+
+int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
+                       int32_t n, int32_t m, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, float* partial, int64_t ldp,
+                       int32_t F, float alpha, float beta, void* stream) {
+  if (!plan) return fail(DGNN_E_BADARG, "spmm_plan: null plan%s", "");
+  if (n < 0 || m < 0 || F < 0) return fail(DGNN_E_BADARG, "spmm_plan: negative size%s", "");
+  if (n == 0 || F == 0) return DGNN_OK;
+  if (!C || ldc < F) return fail(DGNN_E_BADARG, "spmm_plan: bad C%s", "");
+  hipStream_t s = (hipStream_t)stream;
+  // Stages accumulate into C one after another and a row need not appear in stage 0, so C holds
+  // beta*C before the first stage.
+  if (beta != 1.f) {
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(capped_blocks((int64_t)n * F, 8192)), dim3(256), 0, s, C, ldc, n, F, beta);
+    DGNN_HIP(hipGetLastError());
+  }
+  if (plan->nstage <= 0 || !plan->stage_seg_off || plan->stage_seg_off[plan->nstage] == 0) return DGNN_OK;
+  if (!plan->seg || !plan->stage_cut_off || !col || !val || !B)
+    return fail(DGNN_E_BADARG, "spmm_plan: null pointer%s", "");
+  if (ldb < F || ldb % 4 != 0 || !aligned(B, 16))
+    return fail(DGNN_E_BADARG, "spmm_plan: B needs ldb >= F, ldb %% 4 == 0 and a 16-byte aligned base (dgnn_pad_rows_f32)%s", "");
+  if (overlap(B, m, ldb, C, n, ldc, F)) return fail(DGNN_E_BADARG, "spmm_plan: B and C overlap%s", "");
+  const int64_t ncut = plan->stage_cut_off[plan->nstage];
+  if (ncut > 0 && (!partial || !plan->cut || ldp < ldb || ldp % 4 != 0 || !aligned(partial, 16)))
+    return fail(DGNN_E_BADARG, "spmm_plan: cut segments need a 16-byte aligned partial buffer with ldp >= ldb, ldp %% 4 == 0%s", "");
+  const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : ((ldc % 2 == 0 && aligned(C, 8)) ? 2 : 1);
+  for (int32_t st = 0; st < plan->nstage; ++st) {
+    const int64_t s0 = plan->stage_seg_off[st], s1 = plan->stage_seg_off[st + 1];
+    if (s1 > s0) {
+      const int4* seg = reinterpret_cast<const int4*>(plan->seg) + s0;
+      int rc;
+      if (ldb <= 32) rc = launch_stage<8, 8>(vwc, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      else rc = launch_stage<16, 8>(vwc, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      if (rc != DGNN_OK) return rc;
+    }
+    const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
+    if (p1 > p0) {
+      hipLaunchKernelGGL(merge_kernel, dim3((unsigned)(p1 - p0)), dim3(256), 0, s,
+                         reinterpret_cast<const int4*>(plan->cut) + p0, partial, ldp, C, ldc, F);
+      DGNN_HIP(hipGetLastError());
+    }
+  }
+  return DGNN_OK;
 }
 
 }  // extern "C"

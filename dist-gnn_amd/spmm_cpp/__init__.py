@@ -173,3 +173,153 @@ def spmm_csr(A, B, C, alpha=1.0, beta=1.0):
 
 def set_variant(v):
     _check(_lib.dgnn_set_variant(int(v)), 'set_variant')
+
+
+
+
+# --------------------------------------------------------------------------- fast path: work plan
+class _CPlan(ctypes.Structure):          # struct dgnn_plan (include/dgnn_spmm.h)
+    _fields_ = [('nstage', _i32), ('seg', _p), ('stage_seg_off', _p), ('cut', _p),
+                ('stage_cut_off', _p), ('npartial', _i64)]
+
+
+_lib.dgnn_pad_rows_f32.argtypes = [_p, _i64, _p, _i64, _i32, _i32, _p]
+_lib.dgnn_pad_rows_f32.restype = ctypes.c_int
+_lib.dgnn_spmm_plan_f32.argtypes = [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64,
+                                    _i32, _f32, _f32, _p]
+_lib.dgnn_spmm_plan_f32.restype = ctypes.c_int
+
+CHUNK_BYTES = 256            # one group gathers 64 floats of a B row
+L2_BUDGET = 8 << 20          # target bytes of B per (column block, chunk); measured sweet spot on MI355X
+PIECE_LEN = 256              # runs longer than this are cut (bounds the per-stage critical path)
+
+
+def padded_width(F):
+    """Leading dimension that puts every feature row on a 128-byte line."""
+    return (F + 31) // 32 * 32
+
+
+def pad_rows(src, dst=None):
+    """Copy a [n, F] fp32 matrix into a zero-padded [n, padded_width(F)] buffer (returns the buffer)."""
+    sptr, lds = _dense(src, 'src')
+    n, F = src.shape
+    if dst is None:
+        dst = torch.empty(n, padded_width(F), dtype=torch.float32, device=src.device)
+    dptr, ldd = _dense(dst, 'dst')
+    if dst.size(0) != n or dst.size(1) < F:
+        raise RuntimeError('pad_rows: dst has the wrong shape')
+    with torch.cuda.device(src.device):
+        _check(_lib.dgnn_pad_rows_f32(sptr, lds, dptr, ldd, n, F, _stream(src)), 'pad_rows')
+    return dst
+
+
+def default_stage_count(n, m, nnz, F):
+    """Column-block stages for a block: enough that one chunk of one column block of B is about
+    L2_BUDGET, never so many that a (row, column block) run averages under ~16 nonzeros, and a
+    single stage when B has only one or two 64-float chunks (B then sits in the Infinity Cache)."""
+    if padded_width(F) <= 128 or n == 0:
+        return 1
+    by_cache = -(-m * CHUNK_BYTES // L2_BUDGET)
+    by_density = max(1, int(nnz / max(n, 1) / 16))
+    return int(max(1, min(by_cache, by_density, 64)))
+
+
+class SegPlan:
+    """Host-side builder of ``struct dgnn_plan`` for one CsrBlock (integer work, done once).
+
+    Layout and meaning of every array: include/dgnn_spmm.h. Built with torch index ops on the
+    block's device; the result is deterministic for a given block, stage count and piece length.
+    """
+
+    def __init__(self, A, nstage=1, piece_len=PIECE_LEN):
+        dev = A.device
+        rp = A.rowptr.long()
+        n, nnz = A.n, A.nnz
+        nstage = max(1, int(nstage))
+        cbw = max(1, -(-A.m // nstage))
+        self.nstage, self.piece_len = nstage, piece_len
+        i64 = dict(dtype=torch.long, device=dev)
+        if nnz == 0:
+            self.seg = torch.zeros(0, 4, dtype=torch.int32, device=dev)
+            self.cut = torch.zeros(0, 4, dtype=torch.int32, device=dev)
+            self.stage_seg_off = torch.zeros(nstage + 1, dtype=torch.long)
+            self.stage_cut_off = torch.zeros(nstage + 1, dtype=torch.long)
+            self.npartial = 0
+        else:
+            row_idx = torch.repeat_interleave(torch.arange(n, **i64), rp[1:] - rp[:-1])
+            cb = A.col.long() // cbw
+            key = row_idx * nstage + cb                       # non-decreasing in CSR order
+            first = torch.ones(nnz, dtype=torch.bool, device=dev)
+            first[1:] = key[1:] != key[:-1]
+            k0 = torch.nonzero(first).flatten()
+            k1 = torch.cat([k0[1:], torch.tensor([nnz], **i64)])
+            run_row, run_cb = row_idx[k0], cb[k0]
+            del row_idx, cb, key, first
+            pieces = (k1 - k0 + piece_len - 1) // piece_len
+            is_cut = pieces > 1
+            run_of = torch.repeat_interleave(torch.arange(k0.numel(), **i64), pieces)
+            first_piece = torch.cumsum(pieces, 0) - pieces
+            pidx = torch.arange(run_of.numel(), **i64) - first_piece[run_of]
+            pk0 = k0[run_of] + pidx * piece_len
+            pk1 = torch.minimum(pk0 + piece_len, k1[run_of])
+            prow, pcb, pcut = run_row[run_of], run_cb[run_of], is_cut[run_of]
+            pout = torch.where(pcut, torch.cumsum(pcut.long(), 0) - 1, torch.full_like(pk0, -1))
+            order = torch.argsort(pcb * (piece_len + 1) + (piece_len - (pk1 - pk0)), stable=True)
+            self.seg = torch.stack([prow, pk0, pk1, pout], dim=1)[order].int().contiguous()
+            self.stage_seg_off = torch.cat([torch.zeros(1, **i64), torch.cumsum(torch.bincount(pcb, minlength=nstage), 0)]).cpu().contiguous()
+            cut_runs = torch.nonzero(is_cut).flatten()
+            ccnt = pieces[cut_runs]
+            cbase = torch.cumsum(ccnt, 0) - ccnt
+            cut = torch.stack([run_row[cut_runs], cbase, ccnt, torch.zeros_like(ccnt)], dim=1)
+            corder = torch.argsort(run_cb[cut_runs], stable=True)
+            self.cut = cut[corder].int().contiguous()
+            self.stage_cut_off = torch.cat([torch.zeros(1, **i64), torch.cumsum(torch.bincount(run_cb[cut_runs], minlength=nstage), 0)]).cpu().contiguous()
+            self.npartial = int(ccnt.sum().item())
+        self.nseg = self.seg.size(0)
+        self.ncut = self.cut.size(0)
+        self.c = _CPlan(nstage, self.seg.data_ptr(), self.stage_seg_off.data_ptr(), self.cut.data_ptr(),
+                        self.stage_cut_off.data_ptr(), self.npartial)
+        self._partial = None
+
+    def partial(self, ldb, dev):
+        need = max(self.npartial, 1) * ldb
+        if self._partial is None or self._partial.numel() < need:
+            self._partial = torch.empty(need, dtype=torch.float32, device=dev)
+        return self._partial
+
+
+def _plan_for(A, F):
+    ns = default_stage_count(A.n, A.m, A.nnz, F)
+    plans = A.__dict__.setdefault('_plans', {})
+    if ns not in plans:
+        plans[ns] = SegPlan(A, ns)
+    return plans[ns]
+
+
+def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None):
+    """C <- alpha * A @ B[:, :F] + beta * C, fast path. ``B`` is a padded feature block from
+    ``pad_rows`` (16-byte aligned rows); ``C`` is any row-major [n, F] fp32 matrix."""
+    bptr, ldb = _dense(B, 'B')
+    cptr, ldc = _dense(C, 'C')
+    F = C.size(1)
+    if B.size(0) != A.m or C.size(0) != A.n or B.size(1) < F:
+        raise RuntimeError(f'spmm_plan: shape mismatch A[{A.n}x{A.m}] B{tuple(B.shape)} C{tuple(C.shape)}')
+    if not (A.device == B.device == C.device):
+        raise RuntimeError('spmm_plan: operands are on different devices')
+    if plan is None:
+        plan = _plan_for(A, F)
+    with torch.cuda.device(C.device):
+        P = plan.partial(ldb, C.device)
+        rc = _lib.dgnn_spmm_plan_f32(ctypes.byref(plan.c), A.col.data_ptr(), A.val.data_ptr(), A.n, A.m,
+                                     bptr, ldb, cptr, ldc, P.data_ptr(), ldb, F, float(alpha), float(beta),
+                                     _stream(C))
+    _check(rc, 'spmm_plan')
+
+
+def aggregate(A, H, Z, pad_buf=None):
+    """Z += A @ H for a CsrBlock A: the SpMM of one pipeline stage (models/gcn.py:28-29).
+    H may be an unpadded [m, F] matrix (it is copied into a padded block first) or already padded."""
+    F = Z.size(1)
+    if H.size(1) == F and (H.stride(0) % 4 != 0 or H.data_ptr() % 16 != 0 or H.stride(0) != padded_width(F)):
+        H = pad_rows(H, pad_buf)
+    spmm_plan(A, H, Z, 1.0, 1.0)

@@ -84,9 +84,59 @@ int dgnn_spmm_coo_f32(const int32_t* row, const int32_t* col, const float* val,
 int dgnn_idx_i64_to_i32(const int64_t* src, int64_t count, int32_t* dst, void* stream);
 
 /*
- * Kernel-variant selector for benchmarking and A/B tests (0 = automatic choice).
- * Not part of the reference interface; affects only speed, never results
- * beyond fp32 summation order documented per variant in DESIGN.md.
+ * dst[r, 0:F] = src[r, 0:F], dst[r, F:ldd] = 0 for r < n. Produces the 16-byte-aligned feature
+ * block (ldd % 4 == 0; ldd % 32 == 0 makes every row start on a 128-byte line) that
+ * dgnn_spmm_plan_f32 gathers from. In the reference this slot is the `local_feature.clone()`
+ * into the broadcast buffer (light_dist_gnn/models/gcn.py:22-23).
+ */
+int dgnn_pad_rows_f32(const float* src, int64_t lds, float* dst, int64_t ldd,
+                      int32_t n, int32_t F, void* stream);
+
+/*
+ * Work plan of one CSR block for dgnn_spmm_plan_f32 (built once per block; the host-side
+ * builder is dist-gnn_amd/spmm_cpp: SegPlan). Integer data only.
+ *
+ * The column range [0, m) is cut into `nstage` equal blocks. A segment is the run of one
+ * row's nonzeros that falls into one column block: positions [k0, k1) of col/val. Runs
+ * longer than the plan's piece length are cut into pieces; piece p of a cut run has
+ * out = pbase + p (a row of the `partial` buffer), an uncut run has out = -1.
+ *   seg            device, int32[4 * nseg]: {row, k0, k1, out} per entry, grouped by stage,
+ *                  longest first inside a stage
+ *   stage_seg_off  HOST, int64[nstage + 1]: entries of stage s are [off[s], off[s+1])
+ *   cut            device, int32[4 * ncut]: {row, pbase, pieces, 0} per cut run, grouped by stage
+ *   stage_cut_off  HOST, int64[nstage + 1]
+ *   npartial       rows the `partial` buffer must hold (sum of pieces over all cut runs)
+ * No counterpart in the reference (cuSPARSE keeps its own internal buffers, spmm.cpp:26-28).
+ */
+typedef struct dgnn_plan {
+  int32_t nstage;
+  const int32_t* seg;
+  const int64_t* stage_seg_off;
+  const int32_t* cut;
+  const int64_t* stage_cut_off;
+  int64_t npartial;
+} dgnn_plan;
+
+/*
+ * C[n x F] = alpha * A * B + beta * C with a work plan: the fast path.
+ *   col/val        the CSR arrays the plan indexes
+ *   B              ldb >= F, ldb % 4 == 0, 16-byte aligned (see dgnn_pad_rows_f32); columns
+ *                  F..ldb-1 are read but never stored
+ *   partial        device scratch, npartial rows of ldp floats (ldp >= ldb, ldp % 4 == 0,
+ *                  16-byte aligned); may be NULL when the plan cuts nothing
+ * Launches, on `stream`: an optional beta pre-scale, then per stage one SpMM kernel and (if the
+ * stage cut runs) one merge kernel. Same accumulation chain as dgnn_spmm_csr_f32 for every
+ * uncut row; cut rows add their piece sums in piece order (deterministic).
+ * Replaces cusparseSpMM (spmm.cpp:26-28) for callers that keep the block resident across
+ * calls, i.e. the P-stage loop of light_dist_gnn/models/gcn.py:21-29.
+ */
+int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
+                       int32_t n, int32_t m, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, float* partial, int64_t ldp,
+                       int32_t F, float alpha, float beta, void* stream);
+
+/*
+ * Debug/benchmark knob (0 = default). Not part of the reference interface.
  */
 int dgnn_set_variant(int variant);
 int dgnn_get_variant(void);

@@ -145,3 +145,109 @@ def test_errors_are_loud():
     rc = spmm_cpp.lib.dgnn_spmm_csr_f32(None, None, None, 4, 4, 3, None, 8, None, 8, 8,
                                         ctypes.c_float(1), ctypes.c_float(1), None)
     assert rc != 0 and spmm_cpp.lib.dgnn_last_error()
+
+
+# --------------------------------------------------------------------------- fast path (work plan)
+def _gpu_block(row, col, val, n, m):
+    import spmm_cpp
+    dev = torch.device('cuda:0')
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([row, col]).astype(np.int64)), torch.from_numpy(val),
+                                (n, m)).coalesce().to(dev)
+    return spmm_cpp.CsrBlock.from_coo(A)
+
+
+PLAN_CASES = [
+    # n, m, nnz, hubs, F, nstage, piece_len, alpha, beta
+    (1000, 900, 60000, 0, 602, 1, 256, 1.0, 1.0),
+    (1000, 900, 60000, 2, 602, 3, 256, 1.0, 1.0),
+    (3000, 3000, 90000, 3, 256, 4, 64, 1.0, 1.0),
+    (777, 555, 20000, 0, 41, 2, 256, 1.0, 1.0),
+    (512, 512, 9000, 1, 47, 1, 32, 0.5, 2.0),
+    (300, 5000, 30000, 0, 100, 5, 256, 1.0, 0.0),
+    (333, 333, 5000, 0, 172, 2, 256, 1.0, 1.0),
+    (100, 100, 2000, 0, 7, 1, 256, 1.0, 1.0),
+    (100, 100, 2000, 0, 16, 2, 16, -1.0, 0.25),
+    (64, 4096, 3000, 0, 1433, 4, 256, 1.0, 1.0),
+    (4000, 100, 50000, 0, 64, 1, 8, 1.0, 1.0),
+]
+
+
+@pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece,alpha,beta', PLAN_CASES)
+def test_plan_path_matches_oracle(n, m, nnz, hubs, F, nstage, piece, alpha, beta):
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(n + 13 * F + nstage)
+    row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if beta == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), alpha, beta)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    plan = spmm_cpp.SegPlan(blk, nstage, piece)
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+    assert Bp.shape == (m, spmm_cpp.padded_width(F)) and (Bp[:, F:] == 0).all()
+    Cg = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, Cg, alpha, beta, plan)
+    got = Cg.cpu().numpy()
+    rowptr = ref_cpu.coo2csr(row, n)
+    exact = _check(got, want, rowptr, col, val, B, np.nan_to_num(C0), alpha, beta)
+    if plan.ncut == 0:
+        assert exact, 'uncut plans keep the oracle accumulation chain: must be bit-identical'
+    else:   # only rows that were cut may differ from the oracle's bits
+        cut_rows = np.unique(plan.cut.cpu().numpy()[:, 0])
+        mask = np.ones(n, dtype=bool); mask[cut_rows] = False
+        assert np.array_equal(got[mask], want[mask])
+
+
+def test_plan_is_deterministic_and_covers_every_nonzero():
+    import spmm_cpp
+    rng = np.random.default_rng(3)
+    n = m = 5000
+    row, col, val = _rand_csr(rng, n, m, 80000, hub_rows=4)
+    blk = _gpu_block(row, col, val, n, m)
+    p1, p2 = spmm_cpp.SegPlan(blk, 6, 128), spmm_cpp.SegPlan(blk, 6, 128)
+    assert torch.equal(p1.seg, p2.seg) and torch.equal(p1.cut, p2.cut)
+    seg = p1.seg.cpu().numpy().astype(np.int64)
+    covered = np.zeros(val.size, dtype=np.int32)
+    for r, k0, k1, _ in seg:
+        covered[k0:k1] += 1
+        assert (row[k0:k1] == r).all()
+    assert (covered == 1).all()                     # every nonzero in exactly one segment
+    assert (seg[:, 2] - seg[:, 1]).max() <= 128
+    off = p1.stage_seg_off.numpy()
+    cbw = -(-m // 6)
+    for s in range(6):                              # stage s only touches column block s, longest first
+        part = seg[off[s]:off[s + 1]]
+        lens = part[:, 2] - part[:, 1]
+        assert (np.diff(lens) <= 0).all()
+        for r, k0, k1, _ in part[:50]:
+            assert (col[k0:k1] // cbw == s).all()
+    Cs = []
+    dev = torch.device('cuda:0')
+    Bp = spmm_cpp.pad_rows(torch.rand(m, 256, device=dev))
+    for _ in range(3):                              # run-to-run identical bits (no atomics)
+        C = torch.zeros(n, 256, device=dev)
+        spmm_cpp.spmm_plan(blk, Bp, C, 1.0, 0.0, p1)
+        Cs.append(C)
+    assert torch.equal(Cs[0], Cs[1]) and torch.equal(Cs[0], Cs[2])
+
+
+def test_aggregate_helper_and_plan_errors():
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(21)
+    n, m, F = 500, 400, 100
+    row, col, val = _rand_csr(rng, n, m, 9000)
+    blk = _gpu_block(row, col, val, n, m)
+    dev = torch.device('cuda:0')
+    H = rng.standard_normal((m, F), dtype=np.float32)
+    Z0 = rng.standard_normal((n, F), dtype=np.float32)
+    Z = torch.from_numpy(Z0).to(dev)
+    spmm_cpp.aggregate(blk, torch.from_numpy(H).to(dev), Z)
+    assert np.array_equal(Z.cpu().numpy(), ref_cpu.spmm_coo(row, col, val, n, m, H, Z0.copy()))
+    with pytest.raises(RuntimeError):               # unpadded, misaligned B is rejected by the fast path
+        spmm_cpp.spmm_plan(blk, torch.rand(m, F + 1, device=dev)[:, 1:], Z)
+    with pytest.raises(RuntimeError):
+        spmm_cpp.spmm_plan(blk, torch.rand(m + 1, 128, device=dev), Z)

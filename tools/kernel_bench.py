@@ -51,11 +51,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--beta', type=float, default=1.0)
     ap.add_argument('--torch-ref', action='store_true')
+    ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     A, adj = build_graph(args.shape, args.scale, 0, dev)
     deg = (A.rowptr[1:] - A.rowptr[:-1]).float()
     print(f'# degree: mean {deg.mean().item():.1f} max {int(deg.max().item())} p99 {deg.quantile(0.99).item():.0f}', flush=True)
+    sd, _ = torch.sort(deg, descending=True)
+    cs = torch.cumsum(sd, 0) / sd.sum()
+    print('# nnz share of top-K rows/cols: ' + ' '.join(f'{k}:{cs[min(k, A.n) - 1].item():.3f}' for k in (512, 1700, 4096, 8192, 16384, 32768, 65536)), flush=True)
+    plans = {}
     g = torch.Generator(device=dev); g.manual_seed(1)
     for F in [int(x) for x in args.F.split(',')]:
         B = torch.rand(A.m, F, device=dev, generator=g)
@@ -77,7 +82,31 @@ def main():
             print(f'F={F:4d} variant {v}: {med:8.3f} ms (best {best:.3f})  {A.nnz/med/1e6:7.2f} GEdges/s  '
                   f'alg {alg_bytes/med/1e6:7.1f} GB/s = {alg_bytes/med/1e6/8000:.3f} of 8 TB/s  '
                   f'gather {4*F*A.nnz/med/1e9:6.2f} TB/s{err}', flush=True)
-        del B, C
+        C0 = torch.zeros(A.n, F, device=dev)
+        spmm_cpp.set_variant(0)
+        spmm_cpp.spmm_csr(A, B, C0, 1.0, 0.0)
+        Bp = spmm_cpp.pad_rows(B)
+        specs = [x for x in args.plans.split(';') if x]
+        for spec in specs:
+            if spec == 'auto':
+                ns, pl_len = spmm_cpp.default_stage_count(A.n, A.m, A.nnz, F), spmm_cpp.PIECE_LEN
+            else:
+                ns, pl_len = (int(x) for x in spec.split(':'))
+            if (ns, pl_len) not in plans:
+                plans[(ns, pl_len)] = spmm_cpp.SegPlan(A, ns, pl_len)
+                pp = plans[(ns, pl_len)]
+                print(f'# plan nstage={ns} piece={pl_len}: nseg={pp.nseg} ncut={pp.ncut} npartial={pp.npartial}', flush=True)
+            pl = plans[(ns, pl_len)]
+            C.fill_(float('nan'))
+            spmm_cpp.spmm_plan(A, Bp, C, 1.0, 0.0, pl)
+            err = ((C - C0).abs().max() / C0.abs().max()).item()
+            tag = f'{spec}({ns}:{pl_len})' + ('=' if torch.equal(C, C0) else '~')
+            med, best = time_call(lambda: spmm_cpp.spmm_plan(A, Bp, C, 1.0, args.beta, pl), args.iters, args.warmup)
+            pad_ms, _ = time_call(lambda: spmm_cpp.pad_rows(B, Bp), 3, 1)
+            print(f'F={F:4d} plan {tag:>18s}: {med:8.3f} ms (best {best:.3f}) +pad {pad_ms:.3f} ms  {A.nnz/med/1e6:7.2f} GEdges/s  '
+                  f'alg {alg_bytes/med/1e6:7.1f} GB/s = {alg_bytes/med/1e6/8000:.3f} of 8 TB/s  '
+                  f'gather {4*F*A.nnz/med/1e9:6.2f} TB/s  relerr-vs-rowkernel {err:.1e}', flush=True)
+        del B, C, C0
 
 
 if __name__ == '__main__':

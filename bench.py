@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the distributed GCN aggregation path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A *step* is one full GCN training epoch (forward, loss, backward, Adam) of the reference's training
+loop (light_dist_gnn/dist_train.py:36-45) on a dataset-shaped synthetic graph, 1D row-partitioned
+over the N ranks. Default workload = BASELINE.json configs[1]: Reddit shape (232,965 nodes,
+114.6 M edge entries + self loops, 602 features, 41 classes), 2-layer GCN, 256 hidden. The graph is
+generated on the GPU (seeded R-MAT, coo_graph/synthetic.py), normalised, partitioned and converted
+to CSR + work plans BEFORE the timed region; inputs are resident in HBM when timing starts.
+
+Prints ONE JSON line on rank 0. `value` = edges aggregated per second by the whole job: every epoch
+runs 2*L SpMM passes over all nnz(A_hat) entries (L forward + L backward aggregations), so
+value = 2*L*nnz*K / t / 1e9. `roofline` is for the dominant kernel (spmm_stage_kernel), timed
+with HIP events on its launch stream inside the library (dgnn_prof_begin/end) during the timed
+steps. `cpu_baseline` is the CPU oracle (the reference's CPU fallback arithmetic restated in C,
+oracle/spmm_ref.c) on a bounded row sample of the same graph, one host thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'dist-gnn_amd'))
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(nnz, n, m, F, beta_nonzero=True):
+    """8*nnz (col+val) + 4*(n+1) (rowptr) + 4*m*F (B once) + 4*n*F*(1 + [beta != 0])."""
+    return 8 * nnz + 4 * (n + 1) + 4 * m * F + 4 * n * F * (2 if beta_nonzero else 1)
+
+
+def build_rank_graph(args, env):
+    """Generate the full synthetic graph on this rank's GPU, keep this rank's row block."""
+    import coo_graph
+    from coo_graph import synthetic, graph_utils, parted_coo_graph
+    dev = env.device
+    shape = synthetic.SHAPES[args.workload]
+    n = int(shape[0] * args.scale)
+    e = int(shape[1] * (args.scale ** 2 if args.scale < 1 else 1))
+    raw = synthetic.make_dataset(args.workload, seed=args.seed, device=dev, num_nodes=n, num_edges=e)
+    raw = graph_utils.preprocess(args.workload, raw, 'GCN')
+    nnz_total = raw['adj']._nnz()
+    _, parts = parted_coo_graph.partition_dict(raw, env.world_size)
+    mine = parts[env.rank]
+    del raw, parts
+    g = coo_graph.Parted_COO_Graph(args.workload, env.rank, env.world_size, device=dev, attr_dict=mine)
+    return g, n, nnz_total
+
+
+def cpu_baseline(g, widths, budget_s, rank_rows):
+    """Time the CPU oracle on the first `rows` rows of this rank's block (all column blocks = whole rows
+    of A_hat for P = 1), one thread, for each SpMM width of an epoch. Returns GEdges/s."""
+    from oracle import ref_cpu
+    adj = g.adj.coalesce()
+    idx = adj.indices()
+    row = idx[0]
+    n_rows = adj.size(0)
+    # pick a row prefix holding ~budget worth of work at ~1.5e9 fma/s/core
+    rp = torch.zeros(n_rows + 1, dtype=torch.long, device=row.device)
+    rp[1:] = torch.cumsum(torch.bincount(row, minlength=n_rows), 0)
+    per_nnz_fma = float(sum(widths))
+    target_nnz = int(budget_s * 1.5e9 / per_nnz_fma)
+    r1 = int(torch.searchsorted(rp, torch.tensor([target_nnz], device=rp.device)).item())
+    r1 = max(1, min(r1, n_rows))
+    k1 = int(rp[r1].item())
+    rowptr = rp[:r1 + 1].to(torch.int32).cpu().numpy()
+    col = idx[1][:k1].to(torch.int32).cpu().numpy()
+    val = adj.values()[:k1].cpu().numpy()
+    m = adj.size(1)
+    rng = np.random.default_rng(1)
+    total_t = 0.0
+    for F in widths:
+        B = rng.random((m, F), dtype=np.float32)
+        C = np.zeros((r1, F), dtype=np.float32)
+        t0 = time.perf_counter()
+        ref_cpu.spmm_csr(rowptr, col, val, B, C, 1.0, 1.0)
+        total_t += time.perf_counter() - t0
+    return dict(value=round(len(widths) * k1 / total_t / 1e9, 4), unit='GEdges/s', cores=1, kind='port',
+                sample=f'oracle/spmm_ref.c (ATen CPU sparse addmm chain, fmaf) on the first {r1} rows '
+                       f'({k1} nonzeros) of the same normalised graph, SpMM widths {list(widths)} of one epoch, '
+                       f'B [{m} x F] fp32, single thread, {total_t:.1f} s; dense X.W, loss and Adam excluded',
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='reddit', choices=['reddit', 'products', 'cora'])
+    ap.add_argument('--layers', type=int, default=None)
+    ap.add_argument('--hidden', type=int, default=256)
+    ap.add_argument('--scale', type=float, default=1.0, help='shrink the graph (debug only; invalidates the number)')
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU oracle work (0 = skip)')
+    ap.add_argument('--model', default='GCN', choices=['GCN', 'CachedGCN'])
+    args = ap.parse_args()
+    layers = args.layers or {'reddit': 2, 'products': 3, 'cora': 2}[args.workload]
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('DGNN_LOG_DIR', os.path.join('/tmp', f'dgnn_bench_logs_{os.getpid()}'))
+
+    import dist_utils
+    import dist_train
+    import spmm_cpp
+    env = dist_utils.DistEnv(rank, world, 'nccl', echo=False)
+    dev = env.device
+
+    t_build = time.time()
+    g, n_nodes, nnz_total = build_rank_graph(args, env)
+    model = dist_train.build_model(g, env, args.model, args.hidden, layers)
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
+    loss_func = torch.nn.CrossEntropyLoss()
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+
+    def step():
+        return dist_train.train_step(model, optimizer, loss_func, g, env)
+
+    for _ in range(args.warmup):          # also builds the CSR blocks and work plans (once)
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    spmm_cpp.prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, loss = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = spmm_cpp.prof_end()
+    loss_val = float(loss.item())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- figures
+    dims = [g.features.size(1)] + [args.hidden] * (layers - 1) + [g.num_classes]
+    fwd_widths = dims[:-1]                      # aggregation width = layer input width (A_hat H) W
+    bwd_widths = dims[1:]                       # backward aggregates grad_output: layer output width
+    widths = fwd_widths + bwd_widths
+    edges_per_step = len(widths) * nnz_total
+    value = edges_per_step * args.steps / elapsed / 1e9
+    s = g.local_num_nodes
+    local_nnz = g.local_num_edges
+    # algorithmic bytes this rank's SpMM kernels moved in the timed region (one SpMM call per stage block)
+    alg = 0
+    for F in widths:
+        for blk in g.adj_parts:
+            alg += algorithmic_bytes(blk._nnz(), s, blk.size(1), F, True)
+    alg *= args.steps
+    stage_s = prof['stage_ms'] / 1e3
+    launches = max(prof['stage_launches'], 1)
+    achieved = alg / stage_s / 1e9 if stage_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath) and world == 1 and args.workload == 'reddit' and args.scale == 1.0:
+        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+    roofline = dict(bound='hbm', kernel='spmm_stage_kernel', achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    algorithmic_bytes_per_launch=int(alg / launches),
+                    avg_launch_ms=round(prof['stage_ms'] / launches, 4), launches=int(launches),
+                    helper_kernels_ms_per_step=round(prof['other_ms'] / args.steps, 4),
+                    spmm_kernel_gedges_per_s=round(len(widths) * local_nnz * args.steps / stage_s / 1e9, 3) if stage_s > 0 else None,
+                    gather_tb_per_s=round(sum(4 * F for F in widths) * local_nnz * args.steps / stage_s / 1e12, 3) if stage_s > 0 else None)
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_budget > 0:
+        cpu = cpu_baseline(g, widths, args.cpu_budget, s)
+
+    if rank == 0:
+        out = {
+            "metric": "SpMM GEdges/s over the GCN epoch (epoch time in ms_per_step)",
+            "value": round(value, 4), "unit": "GEdges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "epoch_time_s": round(elapsed / args.steps, 6),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic (seeded R-MAT, {args.workload} shape, random-init torch.rand weights)",
+            "config": {"workload": f"{args.workload}-shape {layers}-layer GCN, hidden {args.hidden}, 1D row partition over {world} GPU(s)",
+                       "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
+                       "pipeline": os.environ.get('DGNN_PIPELINE', 'bcast'), "scale": args.scale},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "final_loss": round(loss_val, 4), "setup_s": round(t_build, 1),
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

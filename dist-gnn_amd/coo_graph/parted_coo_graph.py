@@ -1,0 +1,161 @@
+"""Full-graph and per-rank graph containers for the 1D row partition.
+
+API of light_dist_gnn/coo_graph/parted_coo_graph.py (BasicGraph :9-20, GraphCache :23-48,
+COO_Graph :51-93, Parted_COO_Graph :96-115): same class names, constructor arguments,
+attributes (adj, features, labels, *_mask, num_nodes/edges/classes, local_num_nodes,
+local_num_edges, local_labels, local_train_mask, adj_parts) and the same partition arithmetic
+(split_size = ceil(N / P), zero padding of the last block, adj blocks declared (s, s*P)).
+
+Differences: cache files hold plain tensors (sparse matrices as indices/values/size) so they load
+with ``torch.load(weights_only=True)``; ``COO_Graph`` accepts an in-memory dataset dict; the
+partition can be produced in memory (``partition(..., save=False)``) for benchmarks that never
+touch the disk.
+"""
+import os
+
+import torch
+
+from . import datasets, graph_utils
+
+
+def _pack(d):
+    """dict with sparse tensors -> dict of dense tensors / scalars (weights_only-loadable)."""
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor) and v.is_sparse:
+            v = v.coalesce()
+            out[k + '__indices'], out[k + '__values'] = v.indices().clone(), v.values().clone()
+            out[k + '__size'] = torch.tensor(list(v.shape))
+        else:
+            out[k] = v.clone() if isinstance(v, torch.Tensor) else v
+    return out
+
+
+def _unpack(d):
+    out = {}
+    for k, v in d.items():
+        if k.endswith('__indices'):
+            base = k[:-len('__indices')]
+            out[base] = torch.sparse_coo_tensor(v, d[base + '__values'], tuple(d[base + '__size'].tolist()),
+                                                is_coalesced=True)
+        elif not (k.endswith('__values') or k.endswith('__size')):
+            out[k] = v
+    return out
+
+
+class BasicGraph:
+    def __init__(self, d, name, device):
+        self.name, self.device, self.attr_dict = name, device, d
+        self.adj = d['adj'].to(device)
+        self.features = d['features'].to(device)
+        labels = d['labels'].to(device)
+        self.labels = labels.to(torch.float if labels.dim() == 2 else torch.long)
+        self.train_mask, self.val_mask, self.test_mask = (d[k].bool().to(device)
+                                                          for k in ('train_mask', 'val_mask', 'test_mask'))
+        self.num_nodes, self.num_edges, self.num_classes = d['num_nodes'], d['num_edges'], d['num_classes']
+
+    def __repr__(self):
+        counts = ','.join(str(int(m.sum())) for m in (self.train_mask, self.val_mask, self.test_mask))
+        return f'<COO Graph: {self.name}, |V|: {self.num_nodes}, |E|: {self.num_edges}, masks: {counts}>'
+
+
+class GraphCache:
+    @staticmethod
+    def full_graph_path(name, preprocess_for, root=None):
+        return os.path.join(root or datasets.data_root, f'{name}_{preprocess_for}_full.coo_graph')
+
+    @staticmethod
+    def parted_graph_path(name, preprocess_for, rank, num_parts, root=None):
+        dirpath = os.path.join(root or datasets.data_root, f'{name}_{preprocess_for}_{num_parts}_parts')
+        os.makedirs(dirpath, exist_ok=True)
+        return os.path.join(dirpath, f'part_{rank}_of_{num_parts}.coo_graph')
+
+    @staticmethod
+    def save_dict(d, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(_pack(d), path)
+
+    @staticmethod
+    def load_dict(path):
+        return _unpack(torch.load(path, weights_only=True))
+
+
+def partition_dict(attr_dict, num_parts, padding=True):
+    """The arithmetic of COO_Graph.partition (parted_coo_graph.py:63-93) on an in-memory dict:
+    returns (split_size, [per-rank attr dict])."""
+    n = attr_dict['num_nodes']
+    adj, feats = attr_dict['adj'], attr_dict['features']
+    split_size = (n + num_parts - 1) // num_parts
+    pad = split_size * num_parts - n
+    shared = {k: v for k, v in attr_dict.items() if k not in ('adj', 'features')}
+    adj_rows = graph_utils.sparse_2d_split(adj, split_size)
+    feat_rows = list(torch.split(feats, split_size))
+    while len(adj_rows) < num_parts:       # more ranks than non-empty row slabs (tiny graphs)
+        adj_rows.append(torch.sparse_coo_tensor(torch.zeros(2, 0, dtype=torch.long, device=adj.device),
+                                                torch.zeros(0, dtype=adj.dtype, device=adj.device),
+                                                (split_size, adj.size(1)), is_coalesced=True))
+        feat_rows.append(feats.new_zeros(0, feats.size(1)))
+    if padding and pad > 0:
+        short = split_size - feat_rows[-1].size(0)
+        feat_rows[-1] = torch.cat([feat_rows[-1], feats.new_zeros(short, feats.size(1))])
+        for i in range(len(feat_rows) - 1):
+            if feat_rows[i].size(0) < split_size:
+                feat_rows[i] = torch.cat([feat_rows[i], feats.new_zeros(split_size - feat_rows[i].size(0), feats.size(1))])
+        lab = shared['labels']
+        shared['labels'] = torch.cat([lab, lab.new_zeros((pad,) + tuple(lab.shape[1:]))])
+        for key in ('train_mask', 'val_mask', 'test_mask'):
+            shared[key] = torch.cat([shared[key], shared[key].new_zeros(pad)])
+        adj_rows = [torch.sparse_coo_tensor(a.indices(), a.values(), (split_size, split_size * num_parts),
+                                            is_coalesced=True) for a in adj_rows]
+    parts = []
+    for i in range(num_parts):
+        d = dict(shared)
+        d['adj'], d['features'] = adj_rows[i], feat_rows[i]
+        parts.append(d)
+    return split_size, parts
+
+
+class COO_Graph(BasicGraph):
+    def __init__(self, name, preprocess_for='GCN', full_graph_cache_enabled=True, device='cpu', attr_dict=None):
+        self.preprocess_for = preprocess_for
+        self.cache_path = GraphCache.full_graph_path(name, preprocess_for)
+        if attr_dict is not None:                       # already-loaded raw dataset dict
+            cached = graph_utils.preprocess(name, dict(attr_dict), preprocess_for)
+        elif full_graph_cache_enabled and os.path.exists(self.cache_path):
+            cached = GraphCache.load_dict(self.cache_path)
+        else:
+            raw = datasets.load_dataset(name)
+            raw['edge_index'] = raw['edge_index'].long()
+            cached = graph_utils.preprocess(name, raw, preprocess_for)
+            if full_graph_cache_enabled:
+                GraphCache.save_dict(cached, self.cache_path)
+        super().__init__(cached, name, device)
+
+    def partition(self, num_parts, padding=True, save=True):
+        d = dict(self.attr_dict)
+        d.update(adj=self.adj, features=self.features)
+        _, parts = partition_dict(d, num_parts, padding)
+        if save:
+            for i, part in enumerate(parts):
+                GraphCache.save_dict(part, GraphCache.parted_graph_path(self.name, self.preprocess_for, i, num_parts))
+        return parts
+
+
+class Parted_COO_Graph(BasicGraph):
+    def __init__(self, name, rank, num_parts, preprocess_for='GCN', device='cpu', attr_dict=None):
+        self.rank, self.num_parts = rank, num_parts
+        if attr_dict is None:
+            path = GraphCache.parted_graph_path(name, preprocess_for, rank, num_parts)
+            if not os.path.exists(path):
+                raise Exception('Not parted yet. Run COO_Graph.partition() first.', path)
+            attr_dict = GraphCache.load_dict(path)
+        super().__init__(attr_dict, name, device)
+        self.local_num_nodes = self.adj.size(0)
+        self.local_num_edges = self.adj.values().size(0)
+        lo, hi = self.local_num_nodes * rank, self.local_num_nodes * (rank + 1)
+        self.local_labels = self.labels[lo:hi]
+        self.local_train_mask = self.train_mask[lo:hi].bool()
+        self.adj_parts = graph_utils.sparse_2d_split(self.adj, self.local_num_nodes, split_dim=1)
+
+    def __repr__(self):
+        return super().__repr__() + f'<Local: {self.rank}, |V|: {self.local_num_nodes}, |E|: {self.local_num_edges}>'

@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 #include "dgnn_spmm.h"
 
@@ -47,6 +48,23 @@ int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
     if (e_ != hipSuccess)                                                       \
       return fail(DGNN_E_HIP, "%s (line %lld)", hipGetErrorString(e_), __LINE__); \
   } while (0)
+
+// Optional in-library timing of the SpMM kernels with HIP events on the launch stream
+// (dgnn_prof_begin / dgnn_prof_end): bench.py uses it for the live roofline figure.
+struct ProfRec { hipEvent_t a, b; int kind; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+  hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(hipStream_t s_, int kind_) : s(s_), kind(kind_) {
+    if (g_prof_on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+    else a = nullptr;
+  }
+  ~ProfScope() {
+    if (a) { (void)hipEventRecord(b, s); g_prof.push_back({a, b, kind}); }
+  }
+};
 
 template <int VW> struct Vec;
 template <> struct Vec<1> { using T = float; };
@@ -425,6 +443,7 @@ int launch_stage(int vwc, const int4* seg, int32_t nseg, const int32_t* col, con
   const int64_t nchunks = (ldb / 4 + L - 1) / L;
   const int64_t nb = nsegblocks * nchunks;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "stage grid out of range%s (%lld)", "", nb);
+  ProfScope prof(s, 0);
 #define DGNN_STAGE(VWC)                                                                              \
   hipLaunchKernelGGL((spmm_stage_kernel<L, U, VWC>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
                      (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha)
@@ -441,6 +460,31 @@ extern "C" {
 int dgnn_version(void) { return 200; }
 
 const char* dgnn_last_error(void) { return g_err; }
+
+int dgnn_prof_begin(void) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_on = true;
+  return DGNN_OK;
+}
+
+int dgnn_prof_end(double* stage_ms, int64_t* stage_launches, double* other_ms, int64_t* other_launches) {
+  g_prof_on = false;
+  double ms[2] = {0, 0}; int64_t cnt[2] = {0, 0};
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    DGNN_HIP(hipEventSynchronize(r.b));
+    DGNN_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.kind] += t; cnt[r.kind] += 1;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  if (stage_ms) *stage_ms = ms[0];
+  if (stage_launches) *stage_launches = cnt[0];
+  if (other_ms) *other_ms = ms[1];
+  if (other_launches) *other_launches = cnt[1];
+  return DGNN_OK;
+}
 
 int dgnn_set_variant(int variant) { g_variant = variant; return DGNN_OK; }
 int dgnn_get_variant(void) { return g_variant; }
@@ -471,6 +515,7 @@ int dgnn_pad_rows_f32(const float* src, int64_t lds, float* dst, int64_t ldd, in
   if (lds < F || ldd < F || ldd % 4 != 0 || !aligned(dst, 16))
     return fail(DGNN_E_BADARG, "pad_rows: need lds >= F, ldd >= F, ldd %% 4 == 0, dst 16-byte aligned%s", "");
   if (overlap(src, n, lds, dst, n, ldd, F)) return fail(DGNN_E_BADARG, "pad_rows: src and dst overlap%s", "");
+  ProfScope prof((hipStream_t)stream, 1);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(capped_blocks((int64_t)n * (ldd / 4), 16384)), dim3(256), 0,
                      (hipStream_t)stream, src, lds, dst, ldd, n, F);
   DGNN_HIP(hipGetLastError());
@@ -525,6 +570,7 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
   // Stages accumulate into C one after another and a row need not appear in stage 0, so C holds
   // beta*C before the first stage.
   if (beta != 1.f) {
+    ProfScope prof(s, 1);
     hipLaunchKernelGGL(scale_rows_kernel, dim3(capped_blocks((int64_t)n * F, 8192)), dim3(256), 0, s, C, ldc, n, F, beta);
     DGNN_HIP(hipGetLastError());
   }
@@ -549,6 +595,7 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
     if (p1 > p0) {
+      ProfScope prof(s, 1);
       hipLaunchKernelGGL(merge_kernel, dim3((unsigned)(p1 - p0)), dim3(256), 0, s,
                          reinterpret_cast<const int4*>(plan->cut) + p0, partial, ldp, C, ldc, F);
       DGNN_HIP(hipGetLastError());

@@ -1,0 +1,9 @@
+"""Process-group environment, timers and per-rank logs for the 1D-partitioned GCN path.
+
+Keeps the reference's names (light_dist_gnn/dist_utils/__init__.py: ``from .env import DistEnv``).
+"""
+from .env import DistEnv
+from .timer import DistTimer
+from .logger import DistLogger
+
+__all__ = ['DistEnv', 'DistTimer', 'DistLogger']

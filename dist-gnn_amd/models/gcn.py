@@ -1,0 +1,193 @@
+"""Distributed GCN layer over a 1D row partition (CAGNET 1D).
+
+Drop-in for light_dist_gnn/models/gcn.py: ``spmm`` (:9-13), ``broadcast`` (:16-30),
+``DistGCNLayer`` (:33-53), ``GCN`` (:56-72) keep their names, arguments and results.
+
+What changed underneath:
+  * ``spmm(A, B, C)`` runs the hand-written gfx950 kernels through the C ABI (spmm_cpp). Each
+    adjacency block is converted to int32 CSR + a work plan once and cached on the block,
+    instead of two int64->int32 index copies per call (gcn.py:11). There is NO fallback to
+    ``C.addmm_(A, B)`` (gcn.py:13): a missing library or a CPU tensor raises.
+  * ``broadcast`` is a pipeline: the stage-(j+1) feature block travels over RCCL while the
+    stage-j SpMM runs (``inflight`` receive buffers rotate; RCCL runs on its own stream and is
+    ordered against the compute stream by events, never by device-wide synchronisation).
+    Stages are still accumulated in the fixed order src = 0..P-1, so results do not depend on
+    timing and equal the reference's sequential loop.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from dist_utils import DistEnv
+
+_spmm_override = None          # tests install the CPU oracle here to exercise the pipeline on gloo
+
+
+def set_spmm_backend(fn):
+    """Replace the SpMM used by the pipeline (``fn(A_sparse_coo, B, C)`` doing C += A @ B in place).
+    ``None`` restores the HIP operator. Test hook: the product never installs a fallback itself."""
+    global _spmm_override
+    _spmm_override = fn
+
+
+def _csr_block(A):
+    """CsrBlock cached on the sparse tensor object (built on first use)."""
+    import spmm_cpp
+    blk = getattr(A, '_dgnn_csr', None)
+    if blk is None:
+        if not A.is_cuda:
+            raise RuntimeError('spmm: adjacency block is on the CPU; the HIP SpMM has no CPU path '
+                               '(models.gcn.set_spmm_backend is the test hook for gloo runs)')
+        blk = spmm_cpp.CsrBlock.from_coo(A if A.is_coalesced() else A.coalesce())
+        A._dgnn_csr = blk
+    return blk
+
+
+def spmm(A, B, C):
+    """C += A @ B in place (alpha = beta = 1, as gcn.py:11 calls spmm_cusparse)."""
+    if _spmm_override is not None:
+        return _spmm_override(A, B, C)
+    import spmm_cpp
+    spmm_cpp.aggregate(_csr_block(A), B, C)
+
+
+class StagePipeline:
+    """The P-stage broadcast + SpMM loop of gcn.py:16-30, overlapped.
+
+    mode 'bcast'      P rooted broadcasts, ``inflight`` (>= 2) receive buffers: while stage j is
+                      multiplied, stages j+1 .. j+inflight-1 are already in flight.
+    mode 'allgather'  one all-gather of every rank's block (the P broadcasts of a layer pass
+                      are together an all-gather; one collective keeps every xGMI link busy),
+                      then the P SpMMs.
+    Both accumulate src = 0..P-1 in order.
+    """
+
+    def __init__(self, mode=None, inflight=None):
+        self.mode = mode or os.environ.get('DGNN_PIPELINE', 'bcast')
+        self.inflight = max(2, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))
+        self._bufs = {}
+
+    def _buffers(self, like, count):
+        key = (tuple(like.shape), like.dtype, like.device)
+        have = self._bufs.get(key, [])
+        while len(have) < count:
+            have.append(torch.empty_like(like))
+        self._bufs[key] = have
+        return have
+
+    def run(self, adj_parts, feat, tag, fetch=None):
+        """z = sum_src A[rank, src] @ H_src.  ``fetch(src, post, recv)`` lets the cached variant
+        replace a transfer by a stored block (models/cached_gcn.py)."""
+        env = DistEnv.env
+        P, rank, timer = env.world_size, env.rank, env.timer
+        feat = feat.contiguous()
+        z = torch.zeros_like(feat)
+        if P == 1 and fetch is None:
+            with timer.timing_cuda('spmm'):
+                spmm(adj_parts[0], feat, z)
+            return z
+        if self.mode == 'allgather' and fetch is None:
+            gathered = feat.new_empty((P * feat.size(0), feat.size(1)))
+            with timer.timing_cuda('broadcast'):
+                dist.all_gather_into_tensor(gathered, feat, group=env.world_group)
+            s = feat.size(0)
+            for src in range(P):
+                with timer.timing_cuda('spmm'):
+                    spmm(adj_parts[src], gathered[src * s:(src + 1) * s], z)
+            return z
+
+        depth = min(self.inflight, P)
+        bufs = self._buffers(feat, depth)
+        pending = {}
+
+        def post(src):
+            """Start moving H_src: returns immediately, the transfer runs on RCCL's stream."""
+            if fetch is not None:
+                hit = fetch(src, None)
+                if hit is not None:
+                    pending[src] = (None, hit)
+                    return
+            buf = feat if src == rank else bufs[src % depth]
+            work = dist.broadcast(buf, src=src, group=env.world_group, async_op=True)
+            pending[src] = (work, buf)
+
+        for src in range(min(depth - 1, P)):
+            post(src)
+        for src in range(P):
+            if src + depth - 1 < P:
+                post(src + depth - 1)
+            work, block = pending.pop(src)
+            with timer.timing_cuda('broadcast'):
+                if work is not None:
+                    work.wait()
+            if fetch is not None and work is not None:
+                block = fetch(src, block)           # let the cache keep a copy of what arrived
+            with timer.timing_cuda('spmm'):
+                spmm(adj_parts[src], block, z)
+        return z
+
+
+_pipeline = None
+
+
+def pipeline():
+    global _pipeline
+    if _pipeline is None:
+        _pipeline = StagePipeline()
+    return _pipeline
+
+
+def broadcast(local_adj_parts, local_feature, tag):
+    """z_loc = sum over src of A[rank, src] @ H_src  (new [s, F] tensor), gcn.py:16-30."""
+    return pipeline().run(local_adj_parts, local_feature, tag)
+
+
+class DistGCNLayer(torch.autograd.Function):
+    """out = (A_hat H) W with A_hat H aggregated across ranks; gcn.py:33-53.
+    Backward reuses the same (un-transposed) blocks exactly like gcn.py:47 -- correct because the
+    normalised adjacency of an undirected graph is symmetric."""
+
+    @staticmethod
+    def forward(ctx, features, weight, adj_parts, tag):
+        ctx.save_for_backward(features, weight)
+        ctx.adj_parts, ctx.tag = adj_parts, tag
+        z_local = broadcast(adj_parts, features, 'Forward' + tag)
+        with DistEnv.env.timer.timing_cuda('mm'):
+            return torch.mm(z_local, weight)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, weight = ctx.saved_tensors
+        ag = broadcast(ctx.adj_parts, grad_output, 'Backward' + ctx.tag)
+        with DistEnv.env.timer.timing_cuda('mm'):
+            grad_features = torch.mm(ag, weight.t())
+            grad_weight = torch.mm(features.t(), ag)
+        with DistEnv.env.timer.timing_cuda('all_reduce'):
+            DistEnv.env.all_reduce_sum(grad_weight)
+        return grad_features, grad_weight, None, None
+
+
+class GCN(nn.Module):
+    """ReLU GCN; ``num_layers=3`` is the reference model (gcn.py:56-72): weights drawn with
+    torch.rand after torch.manual_seed(0) on the CPU, in layer order, then moved to the device."""
+
+    layer_cls = DistGCNLayer
+
+    def __init__(self, g, env, hidden_dim=16, num_layers=3):
+        super().__init__()
+        self.g, self.env, self.num_layers = g, env, num_layers
+        dims = [g.features.size(1)] + [hidden_dim] * (num_layers - 1) + [g.num_classes]
+        torch.manual_seed(0)
+        for i in range(num_layers):
+            setattr(self, f'weight{i + 1}', nn.Parameter(torch.rand(dims[i], dims[i + 1]).to(env.device)))
+
+    def forward(self, features):
+        h = features
+        for i in range(self.num_layers):
+            h = self.layer_cls.apply(h, getattr(self, f'weight{i + 1}'), self.g.adj_parts, f'L{i + 1}')
+            if i + 1 < self.num_layers:
+                h = F.relu(h)
+        return h

@@ -1,0 +1,22 @@
+"""Offline step: build the normalised graph and write the per-rank part files
+(light_dist_gnn/prepare_data.py). Usage: python prepare_data.py --dataset cora --parts 2 4 8"""
+import argparse
+
+import coo_graph
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dataset', default='cora')
+    ap.add_argument('--parts', type=int, nargs='+', default=[4, 8])
+    ap.add_argument('--no-cache', action='store_true')
+    args = ap.parse_args(argv)
+    g = coo_graph.COO_Graph(args.dataset, full_graph_cache_enabled=not args.no_cache)
+    for p in args.parts:
+        g.partition(p)
+        print(coo_graph.Parted_COO_Graph(args.dataset, 0, p))
+    print(g)
+
+
+if __name__ == '__main__':
+    main()

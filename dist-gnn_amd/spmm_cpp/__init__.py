@@ -171,6 +171,18 @@ def spmm_csr(A, B, C, alpha=1.0, beta=1.0):
     _check(rc, 'spmm_csr')
 
 
+def prof_begin():
+    _check(_lib.dgnn_prof_begin(), 'prof_begin')
+
+
+def prof_end():
+    """-> dict(stage_ms, stage_launches, other_ms, other_launches) since prof_begin()."""
+    a, b = ctypes.c_double(), ctypes.c_double()
+    na, nb = ctypes.c_int64(), ctypes.c_int64()
+    _check(_lib.dgnn_prof_end(ctypes.byref(a), ctypes.byref(na), ctypes.byref(b), ctypes.byref(nb)), 'prof_end')
+    return dict(stage_ms=a.value, stage_launches=na.value, other_ms=b.value, other_launches=nb.value)
+
+
 def set_variant(v):
     _check(_lib.dgnn_set_variant(int(v)), 'set_variant')
 
@@ -316,10 +328,28 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None):
     _check(rc, 'spmm_plan')
 
 
-def aggregate(A, H, Z, pad_buf=None):
+_pad_cache = {}
+
+
+def _pad_buffer(n, ld, dev):
+    """One reusable padded block per (shape, device, stream): calls on one stream are ordered."""
+    key = (n, ld, dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _pad_cache.get(key)
+    if buf is None:
+        if len(_pad_cache) > 64:
+            _pad_cache.clear()
+        buf = _pad_cache[key] = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    return buf
+
+
+def aggregate(A, H, Z):
     """Z += A @ H for a CsrBlock A: the SpMM of one pipeline stage (models/gcn.py:28-29).
-    H may be an unpadded [m, F] matrix (it is copied into a padded block first) or already padded."""
+    H is any row-major [m, F] fp32 matrix; unless its rows already are 128-byte aligned it is
+    first copied into a padded block (dgnn_pad_rows_f32)."""
     F = Z.size(1)
-    if H.size(1) == F and (H.stride(0) % 4 != 0 or H.data_ptr() % 16 != 0 or H.stride(0) != padded_width(F)):
-        H = pad_rows(H, pad_buf)
+    if not (H.dim() == 2 and H.size(1) == F):
+        raise RuntimeError(f'aggregate: H{tuple(H.shape)} does not match Z{tuple(Z.shape)}')
+    if H.stride(0) != padded_width(F) or H.data_ptr() % 128 != 0 or H.stride(1) != 1:
+        with torch.cuda.device(H.device):
+            H = pad_rows(H, _pad_buffer(H.size(0), padded_width(F), H.device))
     spmm_plan(A, H, Z, 1.0, 1.0)

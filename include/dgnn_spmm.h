@@ -136,6 +136,16 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
                        int32_t F, float alpha, float beta, void* stream);
 
 /*
+ * Measurement hooks (no counterpart in the reference). Between dgnn_prof_begin() and
+ * dgnn_prof_end() every kernel launch of dgnn_spmm_plan_f32 / dgnn_pad_rows_f32 is bracketed by
+ * HIP events on its own stream. dgnn_prof_end() waits for them and returns the summed
+ * durations: the stage SpMM kernels (stage_*) and the helper kernels -- pad, beta scale,
+ * merge -- (other_*). Not thread-safe; adds two event records per launch while enabled.
+ */
+int dgnn_prof_begin(void);
+int dgnn_prof_end(double* stage_ms, int64_t* stage_launches, double* other_ms, int64_t* other_launches);
+
+/*
  * Debug/benchmark knob (0 = default). Not part of the reference interface.
  */
 int dgnn_set_variant(int variant);

@@ -1,0 +1,45 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/dgnn_spmm.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'dgnn_spmm.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(dgnn_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(os.path.join(ROOT, 'dist-gnn_amd', 'lib', 'libdgnn_spmm.so'))
+    names = _declared()
+    assert {'dgnn_spmm_csr_f32', 'dgnn_spmm_coo_f32', 'dgnn_coo2csr_i32', 'dgnn_spmm_plan_f32',
+            'dgnn_pad_rows_f32', 'dgnn_last_error', 'dgnn_version'} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in the header but not exported'
+    lib.dgnn_version.restype = ctypes.c_int
+    assert lib.dgnn_version() >= 100
+
+
+def test_argument_checks_need_no_gpu():
+    lib = ctypes.CDLL(os.path.join(ROOT, 'dist-gnn_amd', 'lib', 'libdgnn_spmm.so'))
+    lib.dgnn_last_error.restype = ctypes.c_char_p
+    rc = lib.dgnn_coo2csr_i32(None, ctypes.c_int64(5), ctypes.c_int32(3), None, None)
+    assert rc == 1 and b'null' in lib.dgnn_last_error()
+    rc = lib.dgnn_spmm_plan_f32(None, None, None, 1, 1, None, ctypes.c_int64(4), None, ctypes.c_int64(4), None,
+                                ctypes.c_int64(4), 4, ctypes.c_float(1), ctypes.c_float(1), None)
+    assert rc == 1
+
+
+def test_binding_rejects_cpu_tensors():
+    import pytest
+    import torch
+    import spmm_cpp
+    i = torch.zeros(1, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        spmm_cpp.spmm_cusparse(i, i, torch.ones(1), 1, 1, torch.ones(1, 1), torch.ones(1, 1), 1, 1)
+    assert spmm_cpp.padded_width(602) == 608 and spmm_cpp.padded_width(41) == 64 and spmm_cpp.padded_width(256) == 256
+    assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 602) >= 2
+    assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 41) == 1

@@ -1,0 +1,115 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo, the HIP SpMM swapped for the CPU oracle through
+models.gcn.set_spmm_backend (the test hook). Checks the pipelined ``broadcast``/``DistGCNLayer``/``train``
+against the vectors the reference produced under the same world sizes (tests/golden)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _oracle_spmm(A, B, C):
+    from oracle import ref_cpu
+    idx = A.indices().numpy()
+    Bc = np.ascontiguousarray(B.detach().numpy(), dtype=np.float32)
+    ref_cpu.spmm_coo(idx[0], idx[1], A.values().numpy(), A.size(0), A.size(1), Bc, C.numpy(), 1.0, 1.0)
+
+
+def _worker(rank, world, port, name, mode, inflight, log_dir, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.set_num_threads(1)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DGNN_PIPELINE=mode,
+                          DGNN_INFLIGHT=str(inflight), DGNN_LOG_DIR=log_dir)
+        import coo_graph
+        import dist_train
+        import dist_utils
+        from models import gcn, cached_gcn
+        gcn.set_spmm_backend(_oracle_spmm)
+        env = dist_utils.DistEnv(rank, world, 'gloo', echo=False)
+        gold = np.load(os.path.join(ROOT, 'tests', 'golden', f'{name}_graph.npz'))
+        w = np.load(os.path.join(ROOT, 'tests', 'golden', f'{name}_P{world}.npz'))
+        raw = {"edge_index": torch.from_numpy(gold['edge_index']), "features": torch.from_numpy(gold['raw_features']),
+               "labels": torch.from_numpy(gold['labels']), "train_mask": torch.from_numpy(gold['train_mask']),
+               "val_mask": torch.from_numpy(gold['val_mask']), "test_mask": torch.from_numpy(gold['test_mask']),
+               "num_nodes": int(gold['num_nodes']), "num_edges": gold['edge_index'].shape[1],
+               "num_classes": int(gold['num_classes'])}
+        full = coo_graph.COO_Graph(name, attr_dict=raw)
+        g = coo_graph.Parted_COO_Graph(name, rank, world, attr_dict=full.partition(world, save=False)[rank])
+        res = {}
+        # use the golden (reference-normalised) features so fp32 chains start from identical bits
+        feats = torch.from_numpy(w[f'r{rank}_features'])
+        g.features = feats
+        z = gcn.broadcast(g.adj_parts, feats, 'ForwardL1')
+        res['z_exact'] = bool(np.array_equal(z.numpy(), w[f'r{rank}_layer_z']))
+        res['z_err'] = float(np.abs(z.numpy() - w[f'r{rank}_layer_z']).max())
+        W = torch.from_numpy(w[f'r{rank}_layer_W']).clone().requires_grad_(True)
+        X = feats.clone().requires_grad_(True)
+        y = gcn.DistGCNLayer.apply(X, W, g.adj_parts, 'L1')
+        y.backward(torch.from_numpy(w[f'r{rank}_layer_grad_out']))
+        res['out_err'] = float(np.abs(y.detach().numpy() - w[f'r{rank}_layer_out']).max() / np.abs(w[f'r{rank}_layer_out']).max())
+        res['gf_err'] = float(np.abs(X.grad.numpy() - w[f'r{rank}_layer_grad_features']).max()
+                              / max(np.abs(w[f'r{rank}_layer_grad_features']).max(), 1e-30))
+        res['gw_err'] = float(np.abs(W.grad.numpy() - w[f'r{rank}_layer_grad_weight']).max()
+                              / np.abs(w[f'r{rank}_layer_grad_weight']).max())
+        if w['r0_losses'].size:
+            losses = dist_train.train(g, env, total_epoch=5)
+            res['losses'] = losses
+            res['gold_losses'] = w['r0_losses'].tolist() if rank == 0 else None
+            res['acc_logged'] = sum('Train:' in l for l in open(env.logger.log_fname).read().splitlines()) if rank == 0 else 0
+        z1 = cached_gcn.cached_broadcast(g.adj_parts, feats, 'ForwardL1')
+        z2 = cached_gcn.cached_broadcast(g.adj_parts, feats * 2.0, 'ForwardL1')
+        res['cached_err'] = float(max(np.abs(z1.numpy() - w[f'r{rank}_cached_z1']).max(),
+                                      np.abs(z2.numpy() - w[f'r{rank}_cached_z2']).max()))
+        res['summary'] = env.timer.summary_all()
+        q.put((rank, res))
+        env.barrier_all()
+        torch.distributed.destroy_process_group()
+    except Exception as e:   # surface worker failures in the parent
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+        raise e
+
+
+def _run(world, name, mode='bcast', inflight=2, tmp='/tmp'):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, mode, inflight, tmp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r, res in out.items():
+        assert 'error' not in res, res.get('error')
+    return out
+
+
+@pytest.mark.parametrize('world,name,mode,inflight', [
+    (2, 'tiny', 'bcast', 2), (3, 'tiny', 'bcast', 2), (3, 'ragged', 'bcast', 3), (2, 'ragged', 'allgather', 2),
+    (2, 'directed', 'bcast', 2), (2, 'multilabel', 'bcast', 2), (1, 'tiny', 'bcast', 2)])
+def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
+    out = _run(world, name, mode, inflight, str(tmp_path))
+    for r, res in out.items():
+        assert res['z_exact'], f'rank {r}: aggregation differs from the reference by {res["z_err"]}'
+        assert res['out_err'] <= 1e-5 and res['gf_err'] <= 1e-5 and res['gw_err'] <= 1e-5, res
+        assert res['cached_err'] <= 1e-6, res
+        assert 'spmm' in res['summary'] and 'broadcast' in res['summary'] or world == 1
+    if out[0].get('gold_losses'):
+        got, want = np.array(out[0]['losses']), np.array(out[0]['gold_losses'])
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=6e-5)      # reference logs 4 decimals
+        assert out[0]['acc_logged'] >= 2                                    # epochs 0 and 4 are evaluated

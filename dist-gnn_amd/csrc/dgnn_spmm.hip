@@ -217,17 +217,61 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 // one XCD gather from one 256-byte feature chunk of one column block of B: the L2 working set
 // is (columns per block) x 256 B instead of whole B rows.
 // ---------------------------------------------------------------------------------------
-template <int L, int U, int VWC>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int SEG_MAX = 256;   // longest run a plan may hand to one group (dgnn_plan: piece length)
+
+// C-side access helpers: VWC floats per access, guarded per element against F.
+template <int VWC>
+__device__ __forceinline__ void c_load(const float* p, int fbase, int F, f32x2& a01, f32x2& a23) {
+  if constexpr (VWC == 4) {
+    if (fbase < F) { const float4 t = *reinterpret_cast<const float4*>(p); a01 = {t.x, t.y}; a23 = {t.z, t.w}; }
+  } else if constexpr (VWC == 2) {
+    if (fbase < F) { const float2 t = *reinterpret_cast<const float2*>(p); a01 = {t.x, t.y}; }
+    if (fbase + 2 < F) { const float2 t = *reinterpret_cast<const float2*>(p + 2); a23 = {t.x, t.y}; }
+  } else {
+    if (fbase < F) a01.x = p[0];
+    if (fbase + 1 < F) a01.y = p[1];
+    if (fbase + 2 < F) a23.x = p[2];
+    if (fbase + 3 < F) a23.y = p[3];
+  }
+}
+
+template <int VWC>
+__device__ __forceinline__ void c_store(float* p, int fbase, int F, f32x2 a01, f32x2 a23) {
+  if constexpr (VWC == 4) {
+    if (fbase < F) *reinterpret_cast<float4*>(p) = make_float4(a01.x, a01.y, a23.x, a23.y);
+  } else if constexpr (VWC == 2) {
+    if (fbase < F) *reinterpret_cast<float2*>(p) = make_float2(a01.x, a01.y);
+    if (fbase + 2 < F) *reinterpret_cast<float2*>(p + 2) = make_float2(a23.x, a23.y);
+  } else {
+    if (fbase < F) p[0] = a01.x;
+    if (fbase + 1 < F) p[1] = a01.y;
+    if (fbase + 2 < F) p[2] = a23.x;
+    if (fbase + 3 < F) p[3] = a23.y;
+  }
+}
+
+// Instruction budget of the inner loop (what bounds this kernel once gathers are L2-resident:
+// PMC showed TA 56 % busy, L2 latency 250 cycles, and the SIMDs saturated by ~14 VALU/LDS
+// instructions per gathered float4): a batch of 16 (col, val) entries is turned ONCE into
+// (32-bit byte offset of the B row, alpha*val) pairs and parked in a wave-private LDS strip;
+// every lane of the group then reads two entries per ds_read_b128 at a group-uniform address
+// (LDS broadcast), adds its own lane offset, and issues global_load_dwordx4 with the scalar
+// base of B (saddr form). Per entry and lane: 1/2 LDS read + 1 add + 1 load + 2 packed FMAs.
+template <int U, int VWC, bool WIDE>
 __global__ __launch_bounds__(256) void spmm_stage_kernel(
     const int4* __restrict__ seg, int32_t nseg, uint32_t nsegblocks,
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
     float* __restrict__ P, int64_t ldp, int32_t F, float alpha) {
-  constexpr int G = 64 / L;
+  constexpr int L = 16, G = 4;
+  static_assert(U % 2 == 0, "entries are read two per ds_read_b128");
+  __shared__ uint2 ent_all[4][G][SEG_MAX];      // (row offset or column, alpha*val) of the group's run
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane / L;
   const int li = lane % L;
+  uint2* const ent = ent_all[wave][g];
 
   const uint32_t nb = gridDim.x, b = blockIdx.x;
   const uint32_t q = nb >> 3, r = nb & 7, xcd = b & 7;
@@ -241,72 +285,76 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   int4 s = make_int4(0, 0, 0, -1);             // {row, k0, k1, out}: out < 0 -> accumulate into C[row]
   if (live) s = seg[sidx];
   const int kb = s.y, ke = s.z;
-  const bool fb = fbase < ldb;                  // lane has a float4 of B to gather
   const bool direct = s.w < 0;
+  // lanes past the padded width gather a valid float4 (the row's last one) and never store it
+  const int fgather = min(fbase, (int)ldb - 4);
+  const uint32_t loff = (uint32_t)fgather * 4u;
+  const uint32_t ldb_bytes = (uint32_t)ldb * 4u;
+  const char* const Bbytes = reinterpret_cast<const char*>(B);
 
   float* const dst = direct ? (C + (int64_t)s.x * ldc + fbase) : (P + (int64_t)s.w * ldp + fbase);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (live && direct) {                         // pieces start from 0, direct segments from C
-    if constexpr (VWC == 4) { if (fbase < F) ld_vec<4>(dst, acc); }
-    if constexpr (VWC == 2) {
-      float t[2];
-      if (fbase < F) { ld_vec<2>(dst, t); acc[0] = t[0]; acc[1] = t[1]; }
-      if (fbase + 2 < F) { ld_vec<2>(dst + 2, t); acc[2] = t[0]; acc[3] = t[1]; }
-    }
-    if constexpr (VWC == 1) {
+  f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+  if (live && direct) c_load<VWC>(dst, fbase, F, a01, a23);   // pieces start from 0, direct runs from C
+
+  // Phase 1: the whole run's (col, val) stream -- cold data, read once, HBM/Infinity-Cache
+  // latency -- is fetched up front, all loads in flight together, and parked in LDS. Vector
+  // loads return in order, so a cold load issued between gather rounds would stall every
+  // younger (L2-hit) gather behind it; this way the run pays that latency once.
+  const int len = ke - kb;                      // <= SEG_MAX (plan piece length)
+#pragma unroll 1
+  for (int t0 = 0; t0 * L < len; t0 += 4) {     // 64 entries (8 loads per lane) in flight per trip
+    uint32_t cx[4], vy[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (fbase + e < F) acc[e] = dst[e];
+    for (int t = 0; t < 4; ++t) {               // clamped, branch-free: tail lanes re-read the last entry
+      const int kk = min(kb + li + (t0 + t) * L, ke - 1);
+      cx[t] = (uint32_t)col[kk];
+      vy[t] = __float_as_uint(val[kk]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t x = WIDE ? cx[t] : cx[t] * ldb_bytes;
+      ent[(li + (t0 + t) * L) & (SEG_MAX - 1)] = make_uint2(x, __float_as_uint(alpha * __uint_as_float(vy[t])));
     }
   }
-
-  const float* Bf = B + fbase;
-  for (int k0 = kb; k0 < ke; k0 += L) {
-    const int kk = k0 + li;
-    int cv = 0; float vv = 0.f;
-    if (kk < ke) { cv = col[kk]; vv = alpha * val[kk]; }
-    const int cnt = min(L, ke - k0);
-    int j = 0;
-    for (; j + U <= cnt; j += U) {
-      int c[U]; float v[U];
-      float bb[U][4];
+  // Phase 2: gather rounds, U rows of B in flight per lane.
+  int j = 0;
+#pragma unroll 1
+  for (; j + U <= len; j += U) {
+    uint4 e[U / 2];
 #pragma unroll
-      for (int u = 0; u < U; ++u) bcast_entry<L>(cv, vv, g, j + u, c[u], v[u]);
+    for (int h = 0; h < U / 2; ++h) e[h] = *reinterpret_cast<const uint4*>(&ent[j + 2 * h]);
+    float4 bb[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (fb) ld_vec<4>(Bf + (int64_t)c[u] * ldb, bb[u]);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (fb) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[u], bb[u][e], acc[e]);
-        }
+    for (int u = 0; u < U; ++u) {
+      const uint32_t x = (u & 1) ? e[u / 2].z : e[u / 2].x;
+      if constexpr (WIDE) bb[u] = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)x * ldb_bytes + loff));
+      else bb[u] = *reinterpret_cast<const float4*>(Bbytes + (x + loff));
     }
-    for (; j < cnt; ++j) {
-      int c; float v;
-      bcast_entry<L>(cv, vv, g, j, c, v);
-      if (fb) {
-        float bb[4];
-        ld_vec<4>(Bf + (int64_t)c * ldb, bb);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, bb[e], acc[e]);
-      }
+    for (int u = 0; u < U; ++u) {
+      const float v = __uint_as_float((u & 1) ? e[u / 2].w : e[u / 2].y);
+      const f32x2 vv = {v, v};
+      a01 = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01);
+      a23 = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23);
     }
+  }
+#pragma unroll 1
+  for (; j < len; ++j) {
+    const uint2 e = ent[j];
+    float4 bb;
+    if constexpr (WIDE) bb = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)e.x * ldb_bytes + loff));
+    else bb = *reinterpret_cast<const float4*>(Bbytes + (e.x + loff));
+    const float v = __uint_as_float(e.y);
+    const f32x2 vv = {v, v};
+    a01 = __builtin_elementwise_fma(vv, (f32x2){bb.x, bb.y}, a01);
+    a23 = __builtin_elementwise_fma(vv, (f32x2){bb.z, bb.w}, a23);
   }
 
   if (live) {
     if (!direct) {                              // partial rows are ours: ldp % 4 == 0, 16-B aligned
-      if (fbase < ldp) st_vec<4>(dst, acc);
+      if (fbase < ldp) *reinterpret_cast<float4*>(dst) = make_float4(a01.x, a01.y, a23.x, a23.y);
     } else {
-      if constexpr (VWC == 4) { if (fbase < F) st_vec<4>(dst, acc); }
-      if constexpr (VWC == 2) {
-        float t[2];
-        if (fbase < F) { t[0] = acc[0]; t[1] = acc[1]; st_vec<2>(dst, t); }
-        if (fbase + 2 < F) { t[0] = acc[2]; t[1] = acc[3]; st_vec<2>(dst + 2, t); }
-      }
-      if constexpr (VWC == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (fbase + e < F) dst[e] = acc[e];
-      }
+      c_store<VWC>(dst, fbase, F, a01, a23);
     }
   }
 }
@@ -434,20 +482,20 @@ bool overlap(const float* B, int64_t rows_b, int64_t ldb, const float* C, int64_
   return b0 < c1 && c0 < b1;
 }
 
-template <int L, int U>
-int launch_stage(int vwc, const int4* seg, int32_t nseg, const int32_t* col, const float* val,
+template <int U>
+int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_t* col, const float* val,
                  const float* B, int64_t ldb, float* C, int64_t ldc, float* P, int64_t ldp,
                  int32_t F, float alpha, hipStream_t s) {
-  constexpr int G = 64 / L;
-  const int64_t nsegblocks = ((int64_t)nseg + 4 * G - 1) / (4 * G);
-  const int64_t nchunks = (ldb / 4 + L - 1) / L;
+  const int64_t nsegblocks = ((int64_t)nseg + 15) / 16;          // 4 waves x 4 groups per workgroup
+  const int64_t nchunks = (ldb / 4 + 15) / 16;
   const int64_t nb = nsegblocks * nchunks;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "stage grid out of range%s (%lld)", "", nb);
   ProfScope prof(s, 0);
-#define DGNN_STAGE(VWC)                                                                              \
-  hipLaunchKernelGGL((spmm_stage_kernel<L, U, VWC>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
+#define DGNN_STAGE(VWC, WIDE)                                                                          \
+  hipLaunchKernelGGL((spmm_stage_kernel<U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
                      (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha)
-  if (vwc == 4) DGNN_STAGE(4); else if (vwc == 2) DGNN_STAGE(2); else DGNN_STAGE(1);
+  if (wide) { if (vwc == 4) DGNN_STAGE(4, true); else if (vwc == 2) DGNN_STAGE(2, true); else DGNN_STAGE(1, true); }
+  else { if (vwc == 4) DGNN_STAGE(4, false); else if (vwc == 2) DGNN_STAGE(2, false); else DGNN_STAGE(1, false); }
 #undef DGNN_STAGE
   DGNN_HIP(hipGetLastError());
   return DGNN_OK;
@@ -575,6 +623,8 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
     DGNN_HIP(hipGetLastError());
   }
   if (plan->nstage <= 0 || !plan->stage_seg_off || plan->stage_seg_off[plan->nstage] == 0) return DGNN_OK;
+  if (plan->max_seg_len <= 0 || plan->max_seg_len > SEG_MAX)
+    return fail(DGNN_E_BADARG, "spmm_plan: plan->max_seg_len must be in 1..256%s (%lld)", "", plan->max_seg_len);
   if (!plan->seg || !plan->stage_cut_off || !col || !val || !B)
     return fail(DGNN_E_BADARG, "spmm_plan: null pointer%s", "");
   if (ldb < F || ldb % 4 != 0 || !aligned(B, 16))
@@ -584,13 +634,15 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
   if (ncut > 0 && (!partial || !plan->cut || ldp < ldb || ldp % 4 != 0 || !aligned(partial, 16)))
     return fail(DGNN_E_BADARG, "spmm_plan: cut segments need a 16-byte aligned partial buffer with ldp >= ldb, ldp %% 4 == 0%s", "");
   const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : ((ldc % 2 == 0 && aligned(C, 8)) ? 2 : 1);
+  const bool wide = ((uint64_t)(m > 0 ? m : 1) * (uint64_t)ldb * 4u) >= 0xffffff00ull || g_variant == 2;   // 32-bit row offsets?
   for (int32_t st = 0; st < plan->nstage; ++st) {
     const int64_t s0 = plan->stage_seg_off[st], s1 = plan->stage_seg_off[st + 1];
     if (s1 > s0) {
       const int4* seg = reinterpret_cast<const int4*>(plan->seg) + s0;
       int rc;
-      if (ldb <= 32) rc = launch_stage<8, 8>(vwc, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
-      else rc = launch_stage<16, 8>(vwc, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      if (g_variant == 4) rc = launch_stage<4>(vwc, wide, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      else if (g_variant == 16) rc = launch_stage<16>(vwc, wide, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      else rc = launch_stage<8>(vwc, wide, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
       if (rc != DGNN_OK) return rc;
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];

@@ -192,7 +192,7 @@ def set_variant(v):
 # --------------------------------------------------------------------------- fast path: work plan
 class _CPlan(ctypes.Structure):          # struct dgnn_plan (include/dgnn_spmm.h)
     _fields_ = [('nstage', _i32), ('seg', _p), ('stage_seg_off', _p), ('cut', _p),
-                ('stage_cut_off', _p), ('npartial', _i64)]
+                ('stage_cut_off', _p), ('npartial', _i64), ('max_seg_len', _i32)]
 
 
 _lib.dgnn_pad_rows_f32.argtypes = [_p, _i64, _p, _i64, _i32, _i32, _p]
@@ -247,6 +247,8 @@ class SegPlan:
         dev = A.device
         rp = A.rowptr.long()
         n, nnz = A.n, A.nnz
+        if not 1 <= piece_len <= 256:
+            raise ValueError('piece_len must be in 1..256 (one LDS strip per lane group)')
         nstage = max(1, int(nstage))
         cbw = max(1, -(-A.m // nstage))
         self.nstage, self.piece_len = nstage, piece_len
@@ -290,7 +292,7 @@ class SegPlan:
         self.nseg = self.seg.size(0)
         self.ncut = self.cut.size(0)
         self.c = _CPlan(nstage, self.seg.data_ptr(), self.stage_seg_off.data_ptr(), self.cut.data_ptr(),
-                        self.stage_cut_off.data_ptr(), self.npartial)
+                        self.stage_cut_off.data_ptr(), self.npartial, int(piece_len))
         self._partial = None
 
     def partial(self, ldb, dev):

@@ -51,6 +51,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--beta', type=float, default=1.0)
     ap.add_argument('--torch-ref', action='store_true')
+    ap.add_argument('--plan-variants', default='0')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -91,21 +92,24 @@ def main():
             if spec == 'auto':
                 ns, pl_len = spmm_cpp.default_stage_count(A.n, A.m, A.nnz, F), spmm_cpp.PIECE_LEN
             else:
-                ns, pl_len = (int(x) for x in spec.split(':'))
-            if (ns, pl_len) not in plans:
-                plans[(ns, pl_len)] = spmm_cpp.SegPlan(A, ns, pl_len)
-                pp = plans[(ns, pl_len)]
-                print(f'# plan nstage={ns} piece={pl_len}: nseg={pp.nseg} ncut={pp.ncut} npartial={pp.npartial}', flush=True)
-            pl = plans[(ns, pl_len)]
-            C.fill_(float('nan'))
-            spmm_cpp.spmm_plan(A, Bp, C, 1.0, 0.0, pl)
-            err = ((C - C0).abs().max() / C0.abs().max()).item()
-            tag = f'{spec}({ns}:{pl_len})' + ('=' if torch.equal(C, C0) else '~')
-            med, best = time_call(lambda: spmm_cpp.spmm_plan(A, Bp, C, 1.0, args.beta, pl), args.iters, args.warmup)
-            pad_ms, _ = time_call(lambda: spmm_cpp.pad_rows(B, Bp), 3, 1)
-            print(f'F={F:4d} plan {tag:>18s}: {med:8.3f} ms (best {best:.3f}) +pad {pad_ms:.3f} ms  {A.nnz/med/1e6:7.2f} GEdges/s  '
-                  f'alg {alg_bytes/med/1e6:7.1f} GB/s = {alg_bytes/med/1e6/8000:.3f} of 8 TB/s  '
-                  f'gather {4*F*A.nnz/med/1e9:6.2f} TB/s  relerr-vs-rowkernel {err:.1e}', flush=True)
+                ns, pl_len = (int(x) for x in spec.split(':')[:2])
+            nhot = 0
+            if (ns, pl_len, nhot) not in plans:
+                plans[(ns, pl_len, nhot)] = spmm_cpp.SegPlan(A, ns, pl_len)
+                pp = plans[(ns, pl_len, nhot)]
+                print(f'# plan nstage={ns} piece={pl_len} nhot={nhot}: nseg={pp.nseg} ncut={pp.ncut} npartial={pp.npartial}', flush=True)
+            pl = plans[(ns, pl_len, nhot)]
+            for pv in [int(x) for x in args.plan_variants.split(',')]:
+              spmm_cpp.set_variant(pv)
+              C.fill_(float('nan'))
+              spmm_cpp.spmm_plan(A, Bp, C, 1.0, 0.0, pl)
+              err = ((C - C0).abs().max() / C0.abs().max()).item()
+              tag = f'{spec}({ns}:{pl_len}:{nhot})v{pv}' + ('=' if torch.equal(C, C0) else '~')
+              med, best = time_call(lambda: spmm_cpp.spmm_plan(A, Bp, C, 1.0, args.beta, pl), args.iters, args.warmup)
+              pad_ms, _ = time_call(lambda: spmm_cpp.pad_rows(B, Bp), 3, 1)
+              print(f'F={F:4d} plan {tag:>26s}: {med:8.3f} ms (best {best:.3f}) +pad {pad_ms:.3f} ms  {A.nnz/med/1e6:7.2f} GEdges/s  '
+                    f'alg {alg_bytes/med/1e6:7.1f} GB/s = {alg_bytes/med/1e6/8000:.3f} of 8 TB/s  '
+                    f'gather {4*F*A.nnz/med/1e9:6.2f} TB/s  relerr-vs-rowkernel {err:.1e}', flush=True)
         del B, C, C0
 
 

@@ -80,15 +80,24 @@ class GraphCache:
         return _unpack(torch.load(path, weights_only=True))
 
 
-def partition_dict(attr_dict, num_parts, padding=True):
+class BlockList(list):
+    """``adj_parts``: the list of column blocks A[rank, j]; ``transposed`` optionally holds the
+    blocks (A^T)[rank, j] for a backward pass that is exact on asymmetric graphs."""
+    transposed = None
+
+
+def partition_dict(attr_dict, num_parts, padding=True, with_transpose=False):
     """The arithmetic of COO_Graph.partition (parted_coo_graph.py:63-93) on an in-memory dict:
-    returns (split_size, [per-rank attr dict])."""
+    returns (split_size, [per-rank attr dict]). ``with_transpose`` also stores the row slab of A^T
+    per rank ('adj_t') -- the role of the older partitioner's pre-transposed column slabs
+    (1D_CAGNET/dist_data.py:59-63,84-108)."""
     n = attr_dict['num_nodes']
     adj, feats = attr_dict['adj'], attr_dict['features']
     split_size = (n + num_parts - 1) // num_parts
     pad = split_size * num_parts - n
     shared = {k: v for k, v in attr_dict.items() if k not in ('adj', 'features')}
     adj_rows = graph_utils.sparse_2d_split(adj, split_size)
+    adj_t_rows = graph_utils.sparse_2d_split(adj.t().coalesce(), split_size) if with_transpose else None
     feat_rows = list(torch.split(feats, split_size))
     while len(adj_rows) < num_parts:       # more ranks than non-empty row slabs (tiny graphs)
         adj_rows.append(torch.sparse_coo_tensor(torch.zeros(2, 0, dtype=torch.long, device=adj.device),
@@ -107,10 +116,15 @@ def partition_dict(attr_dict, num_parts, padding=True):
             shared[key] = torch.cat([shared[key], shared[key].new_zeros(pad)])
         adj_rows = [torch.sparse_coo_tensor(a.indices(), a.values(), (split_size, split_size * num_parts),
                                             is_coalesced=True) for a in adj_rows]
+        if adj_t_rows is not None:
+            adj_t_rows = [torch.sparse_coo_tensor(a.indices(), a.values(), (split_size, split_size * num_parts),
+                                                  is_coalesced=True) for a in adj_t_rows]
     parts = []
     for i in range(num_parts):
         d = dict(shared)
         d['adj'], d['features'] = adj_rows[i], feat_rows[i]
+        if adj_t_rows is not None and i < len(adj_t_rows):
+            d['adj_t'] = adj_t_rows[i]
         parts.append(d)
     return split_size, parts
 
@@ -131,10 +145,10 @@ class COO_Graph(BasicGraph):
                 GraphCache.save_dict(cached, self.cache_path)
         super().__init__(cached, name, device)
 
-    def partition(self, num_parts, padding=True, save=True):
+    def partition(self, num_parts, padding=True, save=True, with_transpose=False):
         d = dict(self.attr_dict)
         d.update(adj=self.adj, features=self.features)
-        _, parts = partition_dict(d, num_parts, padding)
+        _, parts = partition_dict(d, num_parts, padding, with_transpose)
         if save:
             for i, part in enumerate(parts):
                 GraphCache.save_dict(part, GraphCache.parted_graph_path(self.name, self.preprocess_for, i, num_parts))
@@ -142,7 +156,8 @@ class COO_Graph(BasicGraph):
 
 
 class Parted_COO_Graph(BasicGraph):
-    def __init__(self, name, rank, num_parts, preprocess_for='GCN', device='cpu', attr_dict=None):
+    def __init__(self, name, rank, num_parts, preprocess_for='GCN', device='cpu', attr_dict=None,
+                 transposed_backward=False):
         self.rank, self.num_parts = rank, num_parts
         if attr_dict is None:
             path = GraphCache.parted_graph_path(name, preprocess_for, rank, num_parts)
@@ -155,7 +170,12 @@ class Parted_COO_Graph(BasicGraph):
         lo, hi = self.local_num_nodes * rank, self.local_num_nodes * (rank + 1)
         self.local_labels = self.labels[lo:hi]
         self.local_train_mask = self.train_mask[lo:hi].bool()
-        self.adj_parts = graph_utils.sparse_2d_split(self.adj, self.local_num_nodes, split_dim=1)
+        self.adj_parts = BlockList(graph_utils.sparse_2d_split(self.adj, self.local_num_nodes, split_dim=1))
+        if transposed_backward:
+            if 'adj_t' not in attr_dict:
+                raise Exception('transposed_backward needs part files written with partition(..., with_transpose=True)')
+            self.adj_parts.transposed = graph_utils.sparse_2d_split(attr_dict['adj_t'].to(device), self.local_num_nodes,
+                                                                    split_dim=1)
 
     def __repr__(self):
         return super().__repr__() + f'<Local: {self.rank}, |V|: {self.local_num_nodes}, |E|: {self.local_num_edges}>'

@@ -3,5 +3,7 @@
 and is outside the aggregation path this package rebuilds.)"""
 from .gcn import GCN, DistGCNLayer, broadcast
 from .cached_gcn import CachedGCN
+from .adaptive_gcn import AdaptiveGCN
+from .gcn_15d import GCN15D
 
-__all__ = ['GCN', 'CachedGCN', 'DistGCNLayer', 'broadcast']
+__all__ = ['GCN', 'CachedGCN', 'AdaptiveGCN', 'GCN15D', 'DistGCNLayer', 'broadcast']

@@ -44,18 +44,24 @@ def use_cache(tag, src):
     return use
 
 
+class _CachePolicy:
+    """Adapter between use_cache() and StagePipeline's policy hooks for one pass."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def cached(self, src):
+        return g_cache[self.tag][src] if use_cache(self.tag, src) else None
+
+    def arrived(self, src, block):
+        g_bcast_counter[self.tag][src] += 1       # a transfer completed: remember the block
+        if g_cache_enabled.get(self.tag, False):
+            g_cache[self.tag][src] = block.clone()
+
+
 def cached_broadcast(local_adj_parts, local_feature, tag):
     g_epoch_counter[tag] += 1
-
-    def fetch(src, arrived):
-        if arrived is None:                       # asked before the transfer: serve from cache?
-            return g_cache[tag][src] if use_cache(tag, src) else None
-        g_bcast_counter[tag][src] += 1            # a transfer completed: remember the block
-        if g_cache_enabled.get(tag, False):
-            g_cache[tag][src] = arrived.clone()
-        return arrived
-
-    return _gcn.pipeline().run(local_adj_parts, local_feature, tag, fetch=fetch)
+    return _gcn.pipeline().run(local_adj_parts, local_feature, tag, policy=_CachePolicy(tag))
 
 
 class CachedDistGCNLayer(torch.autograd.Function):

@@ -63,12 +63,22 @@ class StagePipeline:
                       are together an all-gather; one collective keeps every xGMI link busy),
                       then the P SpMMs.
     Both accumulate src = 0..P-1 in order.
+
+    ``cache_input`` (default on, DGNN_CACHE_INPUT=0 disables): the layer-1 forward pass moves the
+    *input features*, which do not change between epochs. When the same tensor (same storage,
+    same version counter) is aggregated again under the same tag, the blocks received last time
+    are reused and nothing is sent -- lossless, results identical, one of the 2L transfers of an
+    epoch removed. (The reference's plain GCN re-sends them every epoch; its CachedGCN does this
+    by policy, cached_gcn.py:26.)
     """
 
-    def __init__(self, mode=None, inflight=None):
+    def __init__(self, mode=None, inflight=None, cache_input=None):
         self.mode = mode or os.environ.get('DGNN_PIPELINE', 'bcast')
         self.inflight = max(2, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))
+        self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
         self._bufs = {}
+        self._input_cache = {}         # tag -> (key of the source tensor, [block per src])
+        self.transfers = 0             # blocks actually moved (tests / logs)
 
     def _buffers(self, like, count):
         key = (tuple(like.shape), like.dtype, like.device)
@@ -78,55 +88,100 @@ class StagePipeline:
         self._bufs[key] = have
         return have
 
-    def run(self, adj_parts, feat, tag, fetch=None):
-        """z = sum_src A[rank, src] @ H_src.  ``fetch(src, post, recv)`` lets the cached variant
-        replace a transfer by a stored block (models/cached_gcn.py)."""
+    @staticmethod
+    def _tensor_key(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), t.device)
+
+    def run(self, adj_parts, feat, tag, policy=None, group=None, stages=None):
+        """z = sum over stages of A[stage.block] @ H_(stage.src).
+
+        ``stages``: list of (src_rank, block_index) pairs, default [(j, j) for j in range(P)] -- the
+        1D loop; the 1.5D variant passes the subset its replica owns and its column group.
+        ``policy``: object with ``cached(src) -> tensor | None`` (asked before a transfer) and
+        ``arrived(src, block)`` (told after one), used by the cached / adaptive variants.
+        """
         env = DistEnv.env
-        P, rank, timer = env.world_size, env.rank, env.timer
+        rank, timer = env.rank, env.timer
+        group = env.world_group if group is None else group
+        if stages is None:
+            stages = [(j, j) for j in range(env.world_size)]
         feat = feat.contiguous()
-        z = torch.zeros_like(feat)
-        if P == 1 and fetch is None:
+        z = torch.zeros((adj_parts[stages[0][1]].size(0) if stages else feat.size(0), feat.size(1)),
+                        dtype=feat.dtype, device=feat.device)
+        plain = policy is None
+        if plain and len(stages) == 1 and stages[0][0] == rank:
             with timer.timing_cuda('spmm'):
-                spmm(adj_parts[0], feat, z)
+                spmm(adj_parts[stages[0][1]], feat, z)
             return z
-        if self.mode == 'allgather' and fetch is None:
+
+        reuse = None
+        if plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1') and not feat.requires_grad:
+            hit = self._input_cache.get(tag)
+            if hit is not None and hit[0] == self._tensor_key(feat):
+                reuse = hit[1]
+        if reuse is not None:
+            for src, blk in stages:
+                with timer.timing_cuda('spmm'):
+                    spmm(adj_parts[blk], feat if src == rank else reuse[src], z)
+            return z
+        keep = {} if (plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1')
+                      and not feat.requires_grad) else None
+
+        if self.mode == 'allgather' and plain and len(stages) == dist.get_world_size(group):
+            P = len(stages)
             gathered = feat.new_empty((P * feat.size(0), feat.size(1)))
             with timer.timing_cuda('broadcast'):
-                dist.all_gather_into_tensor(gathered, feat, group=env.world_group)
+                dist.all_gather_into_tensor(gathered, feat, group=group)
+            self.transfers += P - 1
             s = feat.size(0)
-            for src in range(P):
+            members = sorted(src for src, _ in stages)
+            for src, blk in stages:
+                pos = members.index(src)
+                block = gathered[pos * s:(pos + 1) * s]
+                if keep is not None and src != rank:
+                    keep[src] = block
                 with timer.timing_cuda('spmm'):
-                    spmm(adj_parts[src], gathered[src * s:(src + 1) * s], z)
+                    spmm(adj_parts[blk], block, z)
+            if keep is not None:
+                self._input_cache[tag] = (self._tensor_key(feat), keep)
             return z
 
-        depth = min(self.inflight, P)
-        bufs = self._buffers(feat, depth)
+        n = len(stages)
+        depth = min(self.inflight, max(n, 1))
+        # a kept block must not be overwritten by a later stage: give every stage its own buffer then
+        bufs = self._buffers(feat, depth) if keep is None else [torch.empty_like(feat) for _ in range(n)]
         pending = {}
 
-        def post(src):
-            """Start moving H_src: returns immediately, the transfer runs on RCCL's stream."""
-            if fetch is not None:
-                hit = fetch(src, None)
+        def post(i):
+            """Start moving the block of stage i: returns at once, the transfer runs on RCCL's stream."""
+            src = stages[i][0]
+            if policy is not None:
+                hit = policy.cached(src)
                 if hit is not None:
-                    pending[src] = (None, hit)
+                    pending[i] = (None, hit)
                     return
-            buf = feat if src == rank else bufs[src % depth]
-            work = dist.broadcast(buf, src=src, group=env.world_group, async_op=True)
-            pending[src] = (work, buf)
+            buf = feat if src == rank else bufs[i % len(bufs)]
+            work = dist.broadcast(buf, src=src, group=group, async_op=True)
+            self.transfers += 1
+            pending[i] = (work, buf)
 
-        for src in range(min(depth - 1, P)):
-            post(src)
-        for src in range(P):
-            if src + depth - 1 < P:
-                post(src + depth - 1)
-            work, block = pending.pop(src)
+        for i in range(min(depth - 1, n)):
+            post(i)
+        for i, (src, blk) in enumerate(stages):
+            if i + depth - 1 < n:
+                post(i + depth - 1)
+            work, block = pending.pop(i)
             with timer.timing_cuda('broadcast'):
                 if work is not None:
                     work.wait()
-            if fetch is not None and work is not None:
-                block = fetch(src, block)           # let the cache keep a copy of what arrived
+            if policy is not None and work is not None:
+                policy.arrived(src, block)
+            if keep is not None and src != rank:
+                keep[src] = block
             with timer.timing_cuda('spmm'):
-                spmm(adj_parts[src], block, z)
+                spmm(adj_parts[blk], block, z)
+        if keep is not None:
+            self._input_cache[tag] = (self._tensor_key(feat), keep)
         return z
 
 
@@ -148,7 +203,9 @@ def broadcast(local_adj_parts, local_feature, tag):
 class DistGCNLayer(torch.autograd.Function):
     """out = (A_hat H) W with A_hat H aggregated across ranks; gcn.py:33-53.
     Backward reuses the same (un-transposed) blocks exactly like gcn.py:47 -- correct because the
-    normalised adjacency of an undirected graph is symmetric."""
+    normalised adjacency of an undirected graph is symmetric. If the block list carries
+    ``transposed`` blocks (Parted_COO_Graph(..., transposed_backward=True)) the backward pass
+    aggregates with (A^T)[rank, :] instead, which is the true gradient on asymmetric graphs too."""
 
     @staticmethod
     def forward(ctx, features, weight, adj_parts, tag):
@@ -161,7 +218,8 @@ class DistGCNLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         features, weight = ctx.saved_tensors
-        ag = broadcast(ctx.adj_parts, grad_output, 'Backward' + ctx.tag)
+        blocks = getattr(ctx.adj_parts, 'transposed', None) or ctx.adj_parts
+        ag = broadcast(blocks, grad_output, 'Backward' + ctx.tag)
         with DistEnv.env.timer.timing_cuda('mm'):
             grad_features = torch.mm(ag, weight.t())
             grad_weight = torch.mm(features.t(), ag)

@@ -258,15 +258,16 @@ __device__ __forceinline__ void c_store(float* p, int fbase, int F, f32x2 a01, f
 // every lane of the group then reads two entries per ds_read_b128 at a group-uniform address
 // (LDS broadcast), adds its own lane offset, and issues global_load_dwordx4 with the scalar
 // base of B (saddr form). Per entry and lane: 1/2 LDS read + 1 add + 1 load + 2 packed FMAs.
-template <int U, int VWC, bool WIDE>
+template <int L, int U, int VWC, bool WIDE>
 __global__ __launch_bounds__(256) void spmm_stage_kernel(
     const int4* __restrict__ seg, int32_t nseg, uint32_t nsegblocks,
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
     float* __restrict__ P, int64_t ldp, int32_t F, float alpha) {
-  constexpr int L = 16, G = 4;
+  constexpr int G = 64 / L;
+  constexpr int SEGM = SEG_MAX * L / 16;        // strip length: 256 entries (L = 16), 128 (L = 8)
   static_assert(U % 2 == 0, "entries are read two per ds_read_b128");
-  __shared__ uint2 ent_all[4][G][SEG_MAX];      // (row offset or column, alpha*val) of the group's run
+  __shared__ uint2 ent_all[4][G][SEGM];         // (row offset or column, alpha*val) of the group's run
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane / L;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const uint32_t x = WIDE ? cx[t] : cx[t] * ldb_bytes;
-      ent[(li + (t0 + t) * L) & (SEG_MAX - 1)] = make_uint2(x, __float_as_uint(alpha * __uint_as_float(vy[t])));
+      ent[(li + (t0 + t) * L) & (SEGM - 1)] = make_uint2(x, __float_as_uint(alpha * __uint_as_float(vy[t])));
     }
   }
   // Phase 2: gather rounds, U rows of B in flight per lane.
@@ -359,17 +360,34 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   }
 }
 
-// C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order); one block per cut segment.
+// C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order). One wave per cut run; a lane owns
+// float4 columns of the (16-B aligned, padded) partial rows and keeps 4 piece loads in flight.
+template <int VWC>
 __global__ __launch_bounds__(256) void merge_kernel(
-    const int4* __restrict__ cut, const float* __restrict__ P, int64_t ldp,
+    const int4* __restrict__ cut, int32_t ncut, const float* __restrict__ P, int64_t ldp,
     float* __restrict__ C, int64_t ldc, int32_t F) {
-  const int4 c4 = cut[blockIdx.x];             // {row, pbase, count, -}
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+  const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (run >= ncut) return;
+  const int4 c4 = cut[run];                    // {row, pbase, count, -}
+  const int lane = threadIdx.x & 63;
+  for (int f = lane * 4; f < F; f += 256) {
     float* c = C + (int64_t)c4.x * ldc + f;
-    float acc = *c;
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    c_load<VWC>(c, f, F, a01, a23);
     const float* p = P + (int64_t)c4.y * ldp + f;
-    for (int s = 0; s < c4.z; ++s) acc += p[(int64_t)s * ldp];
-    *c = acc;
+    int s = 0;
+    for (; s + 4 <= c4.z; s += 4) {
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(p + (int64_t)(s + u) * ldp);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a01.x += t[u].x; a01.y += t[u].y; a23.x += t[u].z; a23.y += t[u].w; }
+    }
+    for (; s < c4.z; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * ldp);
+      a01.x += t.x; a01.y += t.y; a23.x += t.z; a23.y += t.w;
+    }
+    c_store<VWC>(c, f, F, a01, a23);
   }
 }
 
@@ -482,17 +500,18 @@ bool overlap(const float* B, int64_t rows_b, int64_t ldb, const float* C, int64_
   return b0 < c1 && c0 < b1;
 }
 
-template <int U>
+template <int L, int U>
 int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_t* col, const float* val,
                  const float* B, int64_t ldb, float* C, int64_t ldc, float* P, int64_t ldp,
                  int32_t F, float alpha, hipStream_t s) {
-  const int64_t nsegblocks = ((int64_t)nseg + 15) / 16;          // 4 waves x 4 groups per workgroup
-  const int64_t nchunks = (ldb / 4 + 15) / 16;
+  constexpr int G = 64 / L;
+  const int64_t nsegblocks = ((int64_t)nseg + 4 * G - 1) / (4 * G);   // 4 waves x G groups per workgroup
+  const int64_t nchunks = (ldb / 4 + L - 1) / L;
   const int64_t nb = nsegblocks * nchunks;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "stage grid out of range%s (%lld)", "", nb);
   ProfScope prof(s, 0);
-#define DGNN_STAGE(VWC, WIDE)                                                                          \
-  hipLaunchKernelGGL((spmm_stage_kernel<U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
+#define DGNN_STAGE(VWC, WIDE)                                                                             \
+  hipLaunchKernelGGL((spmm_stage_kernel<L, U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
                      (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha)
   if (wide) { if (vwc == 4) DGNN_STAGE(4, true); else if (vwc == 2) DGNN_STAGE(2, true); else DGNN_STAGE(1, true); }
   else { if (vwc == 4) DGNN_STAGE(4, false); else if (vwc == 2) DGNN_STAGE(2, false); else DGNN_STAGE(1, false); }
@@ -640,16 +659,25 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
     if (s1 > s0) {
       const int4* seg = reinterpret_cast<const int4*>(plan->seg) + s0;
       int rc;
-      if (g_variant == 4) rc = launch_stage<4>(vwc, wide, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
-      else if (g_variant == 16) rc = launch_stage<16>(vwc, wide, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
-      else rc = launch_stage<8>(vwc, wide, seg, (int32_t)(s1 - s0), col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      const int32_t ns = (int32_t)(s1 - s0);
+      // 8-lane groups (128-B chunks) when B is at most 256 floats wide: enough chunks for the 8 XCDs to
+      // work on different ones (measured +22 % at F = 256, +25 % at F = 41); 16-lane groups above.
+      const bool narrow = (g_variant == 8) || (g_variant != 16 && ldb <= 256);
+      if (narrow && plan->max_seg_len <= SEG_MAX / 2)
+        rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      else
+        rc = launch_stage<16, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
       if (rc != DGNN_OK) return rc;
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
     if (p1 > p0) {
       ProfScope prof(s, 1);
-      hipLaunchKernelGGL(merge_kernel, dim3((unsigned)(p1 - p0)), dim3(256), 0, s,
-                         reinterpret_cast<const int4*>(plan->cut) + p0, partial, ldp, C, ldc, F);
+      const int32_t nc = (int32_t)(p1 - p0);
+      const int4* cutp = reinterpret_cast<const int4*>(plan->cut) + p0;
+      const dim3 grid((unsigned)((nc + 3) / 4));
+      if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F);
+      else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F);
+      else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F);
       DGNN_HIP(hipGetLastError());
     }
   }

@@ -201,9 +201,8 @@ _lib.dgnn_spmm_plan_f32.argtypes = [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, 
                                     _i32, _f32, _f32, _p]
 _lib.dgnn_spmm_plan_f32.restype = ctypes.c_int
 
-CHUNK_BYTES = 256            # one group gathers 64 floats of a B row
-L2_BUDGET = 8 << 20          # target bytes of B per (column block, chunk); measured sweet spot on MI355X
-PIECE_LEN = 256              # runs longer than this are cut (bounds the per-stage critical path)
+PIECE_LEN = 128              # runs longer than this are cut (bounds the per-stage critical path; <= 128
+                             # lets the kernel use 8-lane groups for narrow feature blocks)
 
 
 def padded_width(F):
@@ -226,14 +225,17 @@ def pad_rows(src, dst=None):
 
 
 def default_stage_count(n, m, nnz, F):
-    """Column-block stages for a block: enough that one chunk of one column block of B is about
-    L2_BUDGET, never so many that a (row, column block) run averages under ~16 nonzeros, and a
-    single stage when B has only one or two 64-float chunks (B then sits in the Infinity Cache)."""
-    if padded_width(F) <= 128 or n == 0:
+    """Column-block stages for a block (measured on MI355X, Reddit-shape sweeps in DESIGN.md):
+    one stage while the padded B fits the Infinity Cache comfortably; otherwise enough stages that one
+    feature chunk of one column block is ~4 MiB (8-lane groups, ld <= 256) or ~16 MiB (16-lane groups),
+    never so many that a (row, column block) run averages under ~16 nonzeros."""
+    ld = padded_width(F)
+    if n == 0 or m * ld * 4 <= (128 << 20):
         return 1
-    by_cache = -(-m * CHUNK_BYTES // L2_BUDGET)
+    chunk_bytes, budget = (128, 4 << 20) if ld <= 256 else (256, 16 << 20)
+    by_cache = -(-m * chunk_bytes // budget)
     by_density = max(1, int(nnz / max(n, 1) / 16))
-    return int(max(1, min(by_cache, by_density, 64)))
+    return int(max(1, min(by_cache, by_density, 16)))
 
 
 class SegPlan:

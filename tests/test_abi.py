@@ -41,5 +41,6 @@ def test_binding_rejects_cpu_tensors():
     with pytest.raises(RuntimeError, match='no CPU path'):
         spmm_cpp.spmm_cusparse(i, i, torch.ones(1), 1, 1, torch.ones(1, 1), torch.ones(1, 1), 1, 1)
     assert spmm_cpp.padded_width(602) == 608 and spmm_cpp.padded_width(41) == 64 and spmm_cpp.padded_width(256) == 256
-    assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 602) >= 2
+    assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 602) == 4
+    assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 256) == 8
     assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 41) == 1

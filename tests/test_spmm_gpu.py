@@ -158,8 +158,10 @@ def _gpu_block(row, col, val, n, m):
 
 PLAN_CASES = [
     # n, m, nnz, hubs, F, nstage, piece_len, alpha, beta
-    (1000, 900, 60000, 0, 602, 1, 256, 1.0, 1.0),
+    (1000, 900, 60000, 0, 602, 1, 128, 1.0, 1.0),
     (1000, 900, 60000, 2, 602, 3, 256, 1.0, 1.0),
+    (1000, 900, 60000, 2, 256, 3, 128, 1.0, 1.0),
+    (1500, 1500, 40000, 1, 100, 2, 100, 1.0, 1.0),
     (3000, 3000, 90000, 3, 256, 4, 64, 1.0, 1.0),
     (777, 555, 20000, 0, 41, 2, 256, 1.0, 1.0),
     (512, 512, 9000, 1, 47, 1, 32, 0.5, 2.0),

@@ -11,16 +11,19 @@
 //   spmm_rows_kernel   general operands (any alignment / leading dimension). One group of L
 //                      lanes owns one output row; strictly ascending accumulation.
 //   spmm_stage_kernel  the fast path: needs a work plan (dgnn_plan) and a B whose rows are
-//                      16-byte aligned (ldb % 4 == 0). Feature chunks of 64 floats, XCD-aware
-//                      chunk-major work order, column-block stages, long rows cut in pieces.
+//                      16-byte aligned (ldb % 4 == 0). Feature chunks of 64 (or 32) floats,
+//                      XCD-aware chunk-major work order, column-block stages, long rows cut
+//                      in pieces.
 //
-// In both, a (col, val) run of a row is read as one coalesced L-entry segment (one entry per
-// lane) and handed lane-to-lane (v_readlane when L == 64, ds_bpermute otherwise); lane li
-// owns VW consecutive floats of the feature chunk; every output element has exactly one
-// accumulator that starts at beta*C and sees its nonzeros in ascending order with fused
-// multiply-adds -- the same chain as ATen's CPU sparse addmm (oracle/spmm_ref.c), so results
-// are bit-identical to the oracle except for rows the plan cuts into pieces (fixed-order
-// piece sums: deterministic, within fp32 rounding of the chain). No atomics anywhere.
+// In both, a (col, val) run of a row is read with coalesced loads, one entry per lane. The row
+// kernel hands entries lane-to-lane (v_readlane when L == 64, ds_bpermute otherwise); the
+// stage kernel parks the whole run as (32-bit B-row byte offset, alpha*val) pairs in a
+// group-private LDS strip and reads it back two entries per ds_read_b128. Lane li owns VW
+// consecutive floats of the feature chunk; every output element has exactly one accumulator
+// that starts at beta*C and sees its nonzeros in ascending order with fused multiply-adds --
+// the same chain as ATen's CPU sparse addmm (oracle/spmm_ref.c), so results are bit-identical
+// to the oracle except for rows the plan cuts into pieces (fixed-order piece sums:
+// deterministic, within fp32 rounding of the chain). No atomics anywhere.
 //
 // 64-wide wavefronts are assumed throughout (gfx950 only).
 

@@ -106,6 +106,8 @@ def main():
     ap.add_argument('--model', default='GCN', choices=['GCN', 'CachedGCN'])
     ap.add_argument('--cache-input', action='store_true',
                     help='reuse the layer-1 input-feature blocks received in the first epoch (lossless; off for the headline number)')
+    ap.add_argument('--transform-first', action='store_true',
+                    help='opt-in A_hat (H W) ordering for layers with F_out < F_in (re-associated fp32; not the headline)')
     args = ap.parse_args()
     layers = args.layers or {'reddit': 2, 'products': 3, 'cora': 2}[args.workload]
 
@@ -119,11 +121,13 @@ def main():
     os.environ.setdefault('MASTER_PORT', '29531')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ.setdefault('DGNN_LOG_DIR', os.path.join('/tmp', f'dgnn_bench_logs_{os.getpid()}'))
+    os.environ['DGNN_TRANSFORM_FIRST'] = '1' if args.transform_first else '0'
     os.environ['DGNN_CACHE_INPUT'] = '1' if args.cache_input else '0'   # every epoch moves every block, like the reference
 
     import dist_utils
     import dist_train
     import spmm_cpp
+    from models import gcn as gcn_mod
     env = dist_utils.DistEnv(rank, world, 'nccl', echo=False)
     dev = env.device
 
@@ -160,6 +164,8 @@ def main():
     # ---- figures
     dims = [g.features.size(1)] + [args.hidden] * (layers - 1) + [g.num_classes]
     fwd_widths = dims[:-1]                      # aggregation width = layer input width (A_hat H) W
+    if args.transform_first:
+        fwd_widths = [min(a, b) for a, b in zip(dims[:-1], dims[1:])]
     bwd_widths = dims[1:]                       # backward aggregates grad_output: layer output width
     widths = fwd_widths + bwd_widths
     edges_per_step = len(widths) * nnz_total
@@ -201,7 +207,7 @@ def main():
             "data": f"synthetic (seeded R-MAT, {args.workload} shape, random-init torch.rand weights)",
             "config": {"workload": f"{args.workload}-shape {layers}-layer GCN, hidden {args.hidden}, 1D row partition over {world} GPU(s)",
                        "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
-                       "pipeline": os.environ.get('DGNN_PIPELINE', 'bcast'), "cache_input": bool(args.cache_input),
+                       "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transform_first": bool(args.transform_first),
                        "scale": args.scale},
             "roofline": roofline, "cpu_baseline": cpu,
             "final_loss": round(loss_val, 4), "setup_s": round(t_build, 1),

@@ -62,7 +62,16 @@ class StagePipeline:
     mode 'allgather'  one all-gather of every rank's block (the P broadcasts of a layer pass
                       are together an all-gather; one collective keeps every xGMI link busy),
                       then the P SpMMs.
-    Both accumulate src = 0..P-1 in order.
+    mode 'auto'       (default) the first time a (tag, shape) is aggregated, both forms are run
+                      and timed on the spot, the slower rank's time decides (all-reduce MAX, so
+                      every rank picks the same form), and the choice sticks. Costs three extra
+                      aggregations in the first epoch; results do not depend on the choice.
+    All accumulate src = 0..P-1 in order, so z is bit-identical in every mode.
+
+    Wire format: when padding a feature row to the kernel's 128-byte row pitch adds <= 1/16 to the
+    bytes (602 -> 608 floats), the owner pads its block once and the padded block travels, so the
+    receivers' SpMMs read it in place; otherwise the [s, F] block travels as is and each receiver
+    pads its copy (dgnn_pad_rows_f32).
 
     ``cache_input`` (default on, DGNN_CACHE_INPUT=0 disables): the layer-1 forward pass moves the
     *input features*, which do not change between epochs. When the same tensor (same storage,
@@ -73,24 +82,157 @@ class StagePipeline:
     """
 
     def __init__(self, mode=None, inflight=None, cache_input=None):
-        self.mode = mode or os.environ.get('DGNN_PIPELINE', 'bcast')
+        self.mode = mode or os.environ.get('DGNN_PIPELINE', 'auto')
+        if self.mode not in ('auto', 'bcast', 'allgather'):
+            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast or allgather')
         self.inflight = max(2, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))
         self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
         self._bufs = {}
         self._input_cache = {}         # tag -> (key of the source tensor, [block per src])
         self.transfers = 0             # blocks actually moved (tests / logs)
+        self.choice = {}               # (tag, rows, width, group size) -> (form, {form: seconds}) picked by 'auto'
 
-    def _buffers(self, like, count):
-        key = (tuple(like.shape), like.dtype, like.device)
+    def _buffers(self, shape, like, count, tag=''):
+        key = (tuple(shape), like.dtype, like.device, tag)
         have = self._bufs.get(key, [])
         while len(have) < count:
-            have.append(torch.empty_like(like))
+            have.append(torch.empty(shape, dtype=like.dtype, device=like.device))
         self._bufs[key] = have
         return have
 
     @staticmethod
     def _tensor_key(t):
         return (t.data_ptr(), t._version, tuple(t.shape), t.device)
+
+    @staticmethod
+    def _wire_width(feat):
+        """Row pitch (floats) of the block on the wire: the kernel's padded pitch when that is cheap."""
+        F = feat.size(1)
+        if not feat.is_cuda or _spmm_override is not None or feat.dtype != torch.float32:
+            return F
+        ld = (F + 31) // 32 * 32
+        return ld if (ld - F) * 16 <= F else F
+
+    def _own_block(self, feat, ld):
+        """This rank's block as it travels: feat itself, or a padded copy [s, ld]."""
+        if ld == feat.size(1):
+            return feat
+        import spmm_cpp
+        return spmm_cpp.pad_rows(feat, self._buffers((feat.size(0), ld), feat, 1, 'own')[0])
+
+    def describe(self):
+        """What 'auto' settled on, for logs and the bench line."""
+        if self.mode != 'auto':
+            return self.mode
+        if not self.choice:
+            return 'auto'
+        return 'auto(' + ', '.join(f'{k[0]}[{k[1]}x{k[2]}]={v[0]}' for k, v in sorted(self.choice.items())) + ')'
+
+    # ---- the two forms -------------------------------------------------------------------
+    def _run_allgather(self, adj_parts, feat, stages, group, z, keep):
+        env = DistEnv.env
+        rank, timer = env.rank, env.timer
+        P, s, F = len(stages), feat.size(0), feat.size(1)
+        ld = self._wire_width(feat)
+        own = self._own_block(feat, ld)
+        gathered = (self._buffers((P * s, ld), feat, 1, 'gather')[0] if keep is None
+                    else feat.new_empty((P * s, ld)))          # kept blocks must not be overwritten
+        with timer.timing_cuda('broadcast'):
+            dist.all_gather_into_tensor(gathered, own, group=group)
+        self.transfers += P                                  # same count as P rooted broadcasts
+        members = sorted(src for src, _ in stages)
+        for src, blk in stages:
+            pos = members.index(src)
+            block = gathered[pos * s:(pos + 1) * s, :F]
+            if keep is not None and src != rank:
+                keep[src] = block
+            with timer.timing_cuda('spmm'):
+                spmm(adj_parts[blk], block, z)
+        return z
+
+    def _run_bcast(self, adj_parts, feat, stages, group, z, keep, policy):
+        env = DistEnv.env
+        rank, timer = env.rank, env.timer
+        n, F = len(stages), feat.size(1)
+        ld = self._wire_width(feat)
+        own = None
+        shape = (feat.size(0), ld)
+        depth = min(self.inflight, max(n, 1))
+        # a kept block must not be overwritten by a later stage: give every stage its own buffer then
+        bufs = (self._buffers(shape, feat, depth, 'recv') if keep is None
+                else [torch.empty(shape, dtype=feat.dtype, device=feat.device) for _ in range(n)])
+        pending = {}
+
+        def post(i):
+            """Start moving the block of stage i: returns at once, the transfer runs on RCCL's stream."""
+            nonlocal own
+            src = stages[i][0]
+            if policy is not None:
+                hit = policy.cached(src)
+                if hit is not None:
+                    pending[i] = (None, hit)
+                    return
+            if src == rank:
+                if own is None:
+                    own = self._own_block(feat, ld)
+                buf = own
+            else:
+                buf = bufs[i % len(bufs)]
+            work = dist.broadcast(buf, src=src, group=group, async_op=True)
+            self.transfers += 1
+            pending[i] = (work, buf[:, :F] if ld != F else buf)
+
+        for i in range(min(depth - 1, n)):
+            post(i)
+        for i, (src, blk) in enumerate(stages):
+            if i + depth - 1 < n:
+                post(i + depth - 1)
+            work, block = pending.pop(i)
+            with timer.timing_cuda('broadcast'):
+                if work is not None:
+                    work.wait()
+            if policy is not None and work is not None:
+                policy.arrived(src, block)
+            if keep is not None and src != rank:
+                keep[src] = block
+            with timer.timing_cuda('spmm'):
+                spmm(adj_parts[blk], block, z)
+        return z
+
+    def _pick_form(self, adj_parts, feat, stages, group, tag):
+        """'auto': time both forms once for this (tag, shape) and keep the faster one."""
+        key = (tag, feat.size(0), feat.size(1), len(stages))
+        hit = self.choice.get(key)
+        if hit is not None:
+            return hit[0]
+        import time
+        sent = self.transfers
+
+        def once(form):
+            z = torch.zeros((adj_parts[stages[0][1]].size(0), feat.size(1)), dtype=feat.dtype, device=feat.device)
+            if feat.is_cuda:
+                torch.cuda.synchronize(feat.device)
+            t0 = time.perf_counter()
+            if form == 'bcast':
+                self._run_bcast(adj_parts, feat, stages, group, z, None, None)
+            else:
+                self._run_allgather(adj_parts, feat, stages, group, z, None)
+            if feat.is_cuda:
+                torch.cuda.synchronize(feat.device)
+            return time.perf_counter() - t0
+
+        with torch.no_grad():
+            once('bcast')                                   # builds CSR blocks, plans and buffers: not timed
+            once('allgather')
+            t = torch.tensor([once('bcast'), once('allgather')], dtype=torch.float64, device=feat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        tb, ta = (float(x) for x in t.tolist())
+        form = 'allgather' if ta < tb else 'bcast'
+        self.choice[key] = (form, {'bcast': tb, 'allgather': ta})
+        self.transfers = sent                               # tuning traffic is not part of the count
+        DistEnv.env.logger.log(f'pipeline auto {tag} [{feat.size(0)}x{feat.size(1)}] P={len(stages)}: '
+                               f'bcast {tb * 1e3:.3f} ms, allgather {ta * 1e3:.3f} ms -> {form}', rank=0)
+        return form
 
     def run(self, adj_parts, feat, tag, policy=None, group=None, stages=None):
         """z = sum over stages of A[stage.block] @ H_(stage.src).
@@ -114,72 +256,25 @@ class StagePipeline:
                 spmm(adj_parts[stages[0][1]], feat, z)
             return z
 
-        reuse = None
-        if plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1') and not feat.requires_grad:
+        cacheable = (plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1')
+                     and not feat.requires_grad)
+        if cacheable:
             hit = self._input_cache.get(tag)
             if hit is not None and hit[0] == self._tensor_key(feat):
-                reuse = hit[1]
-        if reuse is not None:
-            for src, blk in stages:
-                with timer.timing_cuda('spmm'):
-                    spmm(adj_parts[blk], feat if src == rank else reuse[src], z)
-            return z
-        keep = {} if (plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1')
-                      and not feat.requires_grad) else None
+                for src, blk in stages:
+                    with timer.timing_cuda('spmm'):
+                        spmm(adj_parts[blk], feat if src == rank else hit[1][src], z)
+                return z
+        keep = {} if cacheable else None
 
-        if self.mode == 'allgather' and plain and len(stages) == dist.get_world_size(group):
-            P = len(stages)
-            gathered = feat.new_empty((P * feat.size(0), feat.size(1)))
-            with timer.timing_cuda('broadcast'):
-                dist.all_gather_into_tensor(gathered, feat, group=group)
-            self.transfers += P - 1
-            s = feat.size(0)
-            members = sorted(src for src, _ in stages)
-            for src, blk in stages:
-                pos = members.index(src)
-                block = gathered[pos * s:(pos + 1) * s]
-                if keep is not None and src != rank:
-                    keep[src] = block
-                with timer.timing_cuda('spmm'):
-                    spmm(adj_parts[blk], block, z)
-            if keep is not None:
-                self._input_cache[tag] = (self._tensor_key(feat), keep)
-            return z
-
-        n = len(stages)
-        depth = min(self.inflight, max(n, 1))
-        # a kept block must not be overwritten by a later stage: give every stage its own buffer then
-        bufs = self._buffers(feat, depth) if keep is None else [torch.empty_like(feat) for _ in range(n)]
-        pending = {}
-
-        def post(i):
-            """Start moving the block of stage i: returns at once, the transfer runs on RCCL's stream."""
-            src = stages[i][0]
-            if policy is not None:
-                hit = policy.cached(src)
-                if hit is not None:
-                    pending[i] = (None, hit)
-                    return
-            buf = feat if src == rank else bufs[i % len(bufs)]
-            work = dist.broadcast(buf, src=src, group=group, async_op=True)
-            self.transfers += 1
-            pending[i] = (work, buf)
-
-        for i in range(min(depth - 1, n)):
-            post(i)
-        for i, (src, blk) in enumerate(stages):
-            if i + depth - 1 < n:
-                post(i + depth - 1)
-            work, block = pending.pop(i)
-            with timer.timing_cuda('broadcast'):
-                if work is not None:
-                    work.wait()
-            if policy is not None and work is not None:
-                policy.arrived(src, block)
-            if keep is not None and src != rank:
-                keep[src] = block
-            with timer.timing_cuda('spmm'):
-                spmm(adj_parts[blk], block, z)
+        form = self.mode
+        can_gather = plain and len(stages) == dist.get_world_size(group) and len(stages) > 1
+        if form == 'auto':
+            form = self._pick_form(adj_parts, feat, stages, group, tag) if can_gather else 'bcast'
+        if form == 'allgather' and can_gather:
+            self._run_allgather(adj_parts, feat, stages, group, z, keep)
+        else:
+            self._run_bcast(adj_parts, feat, stages, group, z, keep, policy)
         if keep is not None:
             self._input_cache[tag] = (self._tensor_key(feat), keep)
         return z
@@ -193,6 +288,12 @@ def pipeline():
     if _pipeline is None:
         _pipeline = StagePipeline()
     return _pipeline
+
+
+def transform_first():
+    """DGNN_TRANSFORM_FIRST=1: layers whose output is narrower than their input multiply by W before
+    aggregating. Read at call time so tests can flip it."""
+    return os.environ.get('DGNN_TRANSFORM_FIRST', '0') == '1'
 
 
 def broadcast(local_adj_parts, local_feature, tag):
@@ -211,8 +312,17 @@ class DistGCNLayer(torch.autograd.Function):
     def forward(ctx, features, weight, adj_parts, tag):
         ctx.save_for_backward(features, weight)
         ctx.adj_parts, ctx.tag = adj_parts, tag
+        timer = DistEnv.env.timer
+        if transform_first() and weight.size(1) < features.size(1):
+            # opt-in A_hat (H W): aggregate at the narrower output width (Reddit layer 1: 256 instead of
+            # 602 floats per gathered row). Same mathematics, different fp32 association than gcn.py:39-41,
+            # so it is off by default; the backward formulas below hold unchanged. The tag suffix keeps
+            # this temporary out of the input-feature cache.
+            with timer.timing_cuda('mm'):
+                hw = torch.mm(features, weight)
+            return broadcast(adj_parts, hw, 'Forward' + tag + 'T')
         z_local = broadcast(adj_parts, features, 'Forward' + tag)
-        with DistEnv.env.timer.timing_cuda('mm'):
+        with timer.timing_cuda('mm'):
             return torch.mm(z_local, weight)
 
     @staticmethod

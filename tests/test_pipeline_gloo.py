@@ -75,6 +75,8 @@ def _worker(rank, world, port, name, mode, inflight, log_dir, q):
         res['cached_err'] = float(max(np.abs(z1.numpy() - w[f'r{rank}_cached_z1']).max(),
                                       np.abs(z2.numpy() - w[f'r{rank}_cached_z2']).max()))
         res['summary'] = env.timer.summary_all()
+        res['pipeline'] = gcn.pipeline().describe()
+        res['choices'] = {k: v[0] for k, v in gcn.pipeline().choice.items()}
         q.put((rank, res))
         env.barrier_all()
         torch.distributed.destroy_process_group()
@@ -101,7 +103,8 @@ def _run(world, name, mode='bcast', inflight=2, tmp='/tmp'):
 
 @pytest.mark.parametrize('world,name,mode,inflight', [
     (2, 'tiny', 'bcast', 2), (3, 'tiny', 'bcast', 2), (3, 'ragged', 'bcast', 3), (2, 'ragged', 'allgather', 2),
-    (2, 'directed', 'bcast', 2), (2, 'multilabel', 'bcast', 2), (1, 'tiny', 'bcast', 2)])
+    (2, 'directed', 'bcast', 2), (2, 'multilabel', 'bcast', 2), (1, 'tiny', 'bcast', 2),
+    (2, 'tiny', 'auto', 2), (3, 'ragged', 'auto', 2)])
 def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
     out = _run(world, name, mode, inflight, str(tmp_path))
     for r, res in out.items():
@@ -109,6 +112,9 @@ def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
         assert res['out_err'] <= 1e-5 and res['gf_err'] <= 1e-5 and res['gw_err'] <= 1e-5, res
         assert res['cached_err'] <= 1e-6, res
         assert 'spmm' in res['summary'] and 'broadcast' in res['summary'] or world == 1
+        if mode == 'auto':       # every rank settled on the same form for every (tag, shape) it tuned
+            assert res['choices'] and res['choices'] == out[0]['choices'], (res['choices'], out[0]['choices'])
+            assert set(res['choices'].values()) <= {'bcast', 'allgather'} and res['pipeline'].startswith('auto(')
     if out[0].get('gold_losses'):
         got, want = np.array(out[0]['losses']), np.array(out[0]['gold_losses'])
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=6e-5)      # reference logs 4 decimals

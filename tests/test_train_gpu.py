@@ -94,3 +94,29 @@ def test_cpu_tensors_fail_loudly_in_the_model_path(env):
     A = torch.sparse_coo_tensor(torch.tensor([[0], [0]]), torch.tensor([1.0]), (1, 1)).coalesce()
     with pytest.raises(RuntimeError, match='no CPU path'):
         gcn.spmm(A, torch.ones(1, 4), torch.zeros(1, 4))
+
+
+@pytest.mark.parametrize('F', [602, 100, 256, 41])
+def test_transfer_forms_over_rccl_world1(env, F):
+    """Both transfer forms of the stage pipeline (rooted broadcast, all-gather) through RCCL with one
+    rank: the own block goes through the wire format (padded in flight for F = 602, as is otherwise) and
+    the SpMM reads the received buffer. Must equal the direct single-stage SpMM bit for bit."""
+    from models import gcn
+    dev = env.device
+    g = torch.Generator().manual_seed(F)
+    n = 3000
+    idx = torch.randint(0, n, (2, 60000), generator=g)
+    A = torch.sparse_coo_tensor(idx, torch.rand(60000, generator=g), (n, n)).coalesce().to(dev)
+    H = torch.rand(n, F, generator=g).to(dev)
+    want = torch.zeros(n, F, device=dev)
+    gcn.spmm(A, H, want)
+    pipe = gcn.StagePipeline(mode='bcast')
+    assert pipe._wire_width(H) == (608 if F == 602 else F)
+    stages = [(0, 0)]
+    z1 = pipe._run_bcast([A], H, stages, env.world_group, torch.zeros(n, F, device=dev), None, None)
+    z2 = pipe._run_allgather([A], H, stages, env.world_group, torch.zeros(n, F, device=dev), None)
+    keep = {}
+    z3 = pipe._run_bcast([A], H, stages, env.world_group, torch.zeros(n, F, device=dev), keep, None)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, want) and torch.equal(z2, want) and torch.equal(z3, want)
+    assert pipe.transfers == 3

@@ -149,6 +149,30 @@ def scenario_input_cache(env, rank, world, gold_dir):
     return res
 
 
+def scenario_transform_first(env, rank, world, gold_dir):
+    import coo_graph
+    from models import gcn
+    gold = np.load(os.path.join(gold_dir, 'tiny_graph.npz'))
+    full = coo_graph.COO_Graph('tiny', attr_dict=_raw(gold))
+    g = coo_graph.Parted_COO_Graph('tiny', rank, world, attr_dict=full.partition(world, save=False)[rank])
+    torch.manual_seed(3)
+    W = torch.rand(g.features.size(1), 5)
+    G = torch.rand(g.local_num_nodes, 5)
+    res = {}
+    for flag in ('0', '1'):
+        os.environ['DGNN_TRANSFORM_FIRST'] = flag
+        X = g.features.clone().requires_grad_(True)
+        Wp = W.clone().requires_grad_(True)
+        t0 = gcn.pipeline().transfers
+        y = gcn.DistGCNLayer.apply(X, Wp, g.adj_parts, 'L1')
+        y.backward(G)
+        res[flag] = (y.detach().double(), X.grad.double(), Wp.grad.double())
+    os.environ['DGNN_TRANSFORM_FIRST'] = '0'
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    return dict(out=rel(res['1'][0], res['0'][0]), dx=rel(res['1'][1], res['0'][1]), dw=rel(res['1'][2], res['0'][2]),
+                wide=g.features.size(1))
+
+
 def _worker(rank, world, port, scenario, log_dir, q):
     try:
         for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
@@ -217,6 +241,15 @@ def test_adaptive_policy(tmp_path):
         # 4 epochs x (layer1, layer2, 2 backward passes) x 1 remote block; layer1 sent once; layer2 twice when reused
         assert res['never']['transfers'] == 2 * (1 + 4 + 8)
         assert res['always']['transfers'] == 2 * (1 + 2 + 8)
+
+
+def test_transform_first_is_the_same_layer(tmp_path):
+    """Opt-in A_hat (H W) ordering: same layer output within fp32 re-association, identical backward."""
+    out = _run(2, 'transform_first', str(tmp_path))
+    for r, res in out.items():
+        assert res['wide'] > 5
+        assert 0 < res['out'] <= 1e-5, res            # re-associated (not bit-equal), within the 1e-5 bar
+        assert res['dx'] == 0.0 and res['dw'] == 0.0, res
 
 
 def test_input_cache_is_lossless(tmp_path):

@@ -444,6 +444,30 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
   }
 }
 
+// dst[r, 0:F] = src[idx[r], 0:F]; dst[r, F:ldd] = 0. One float4 of dst per thread; a row of dst is
+// written by consecutive lanes (coalesced 16-B stores), the source row is read the same way.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                          const int32_t* __restrict__ idx,
+                                                          float* __restrict__ dst, int64_t ldd,
+                                                          int32_t k, int32_t F, bool src_vec4) {
+  const int64_t q4 = ldd / 4;
+  const int64_t total = (int64_t)k * q4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / q4;
+    const int f = (int)(t - r * q4) * 4;
+    const float* s = src + (int64_t)idx[r] * lds + f;
+    float o[4];
+    if (src_vec4 && f + 4 <= F) {
+      ld_vec<4>(s, o);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f + e < F) ? s[e] : 0.f;
+    }
+    st_vec<4>(dst + r * ldd + f, o);
+  }
+}
+
 unsigned capped_blocks(int64_t work, unsigned cap) {
   const int64_t b = (work + 255) / 256;
   return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -588,6 +612,23 @@ int dgnn_pad_rows_f32(const float* src, int64_t lds, float* dst, int64_t ldd, in
   ProfScope prof((hipStream_t)stream, 1);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(capped_blocks((int64_t)n * (ldd / 4), 16384)), dim3(256), 0,
                      (hipStream_t)stream, src, lds, dst, ldd, n, F);
+  DGNN_HIP(hipGetLastError());
+  return DGNN_OK;
+}
+
+int dgnn_gather_rows_f32(const float* src, int64_t lds, int32_t nsrc, const int32_t* idx, int32_t k,
+                         float* dst, int64_t ldd, int32_t F, void* stream) {
+  if (k < 0 || F < 0 || nsrc < 0) return fail(DGNN_E_BADARG, "gather_rows: negative size%s", "");
+  if (k == 0 || ldd == 0) return DGNN_OK;
+  if (!src || !dst || !idx) return fail(DGNN_E_BADARG, "gather_rows: null pointer%s", "");
+  if (nsrc == 0) return fail(DGNN_E_BADARG, "gather_rows: rows requested from an empty source%s", "");
+  if (lds < F || ldd < F || ldd % 4 != 0 || !aligned(dst, 16))
+    return fail(DGNN_E_BADARG, "gather_rows: need lds >= F, ldd >= F, ldd %% 4 == 0, dst 16-byte aligned%s", "");
+  if (overlap(src, nsrc, lds, dst, k, ldd, F)) return fail(DGNN_E_BADARG, "gather_rows: src and dst overlap%s", "");
+  const bool src_vec4 = (lds % 4 == 0) && aligned(src, 16);
+  ProfScope prof((hipStream_t)stream, 1);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(capped_blocks((int64_t)k * (ldd / 4), 16384)), dim3(256), 0,
+                     (hipStream_t)stream, src, lds, idx, dst, ldd, k, F, src_vec4);
   DGNN_HIP(hipGetLastError());
   return DGNN_OK;
 }

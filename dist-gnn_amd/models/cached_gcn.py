@@ -78,7 +78,7 @@ class CachedDistGCNLayer(torch.autograd.Function):
         features, weight = ctx.saved_tensors
         ag = cached_broadcast(ctx.adj_parts, grad_output, 'Backward' + ctx.tag)
         with DistEnv.env.timer.timing_cuda('mm'):
-            grad_features = torch.mm(ag, weight.t())
+            grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
             grad_weight = torch.mm(features.t(), ag)
         with DistEnv.env.timer.timing_cuda('all_reduce'):
             DistEnv.env.all_reduce_sum(grad_weight)

@@ -24,13 +24,82 @@ import torch.nn.functional as F
 from dist_utils import DistEnv
 
 _spmm_override = None          # tests install the CPU oracle here to exercise the pipeline on gloo
+_gather_override = None
 
 
-def set_spmm_backend(fn):
-    """Replace the SpMM used by the pipeline (``fn(A_sparse_coo, B, C)`` doing C += A @ B in place).
-    ``None`` restores the HIP operator. Test hook: the product never installs a fallback itself."""
-    global _spmm_override
+def set_spmm_backend(fn, gather=None):
+    """Replace the SpMM used by the pipeline (``fn(A_sparse_coo, B, C)`` doing C += A @ B in place) and,
+    optionally, the row gather of the needed-rows transfer (``gather(src, idx_int32, dst)``).
+    ``None`` restores the HIP operators. Test hook: the product never installs a fallback itself."""
+    global _spmm_override, _gather_override
     _spmm_override = fn
+    _gather_override = gather
+
+
+def _gather_rows(src, idx, dst):
+    """dst[r, :F] = src[idx[r]] (dst may be wider: zero fill) with the HIP kernel dgnn_gather_rows_f32."""
+    if _gather_override is not None:
+        return _gather_override(src, idx, dst)
+    import spmm_cpp
+    return spmm_cpp.gather_rows(src, idx, dst)
+
+
+class NeededRows:
+    """Needed-rows-only transfer (1D_CAGNET/dist_1d.py:33-50 ``p2p_broadcast`` with
+    ``nz_col_dict``, dist_data.py:96-101): block A[rank, src] only reads the rows of H_src whose column
+    holds a nonzero, so only those travel. Built once per block list:
+
+      cols[src]      sorted distinct columns of A[rank, src]          (what this rank needs from src)
+      blocks[src]    A[rank, src] with its columns renumbered 0..k-1 in the same order: the received
+                     rows ARE its B operand, nothing is scattered back. The renumbering is monotone,
+                     so every row keeps its nonzeros in the same order and z stays bit-identical.
+      send_idx[dst]  rows of this rank's H that dst needs (int32), learnt in one all-to-all at set-up
+      K[dst][src]    row counts, known to every rank (sizes of every message)
+    """
+
+    def __init__(self, adj_parts, group):
+        env = DistEnv.env
+        P, rank = env.world_size, env.rank
+        if dist.get_world_size(group) != P or len(adj_parts) != P:
+            raise RuntimeError('NeededRows: only the 1D layout over the world group is supported')
+        dev = adj_parts[0].device
+        self.cols, self.blocks = [], []
+        for src in range(P):
+            A = adj_parts[src] if adj_parts[src].is_coalesced() else adj_parts[src].coalesce()
+            idx = A.indices()
+            if src == rank:                       # the own block reads the local features in place
+                self.cols.append(torch.zeros(0, dtype=torch.long, device=dev))
+                self.blocks.append(A)
+                continue
+            cols, inv = torch.unique(idx[1], sorted=True, return_inverse=True)
+            blk = torch.sparse_coo_tensor(torch.stack([idx[0], inv]), A.values(), (A.size(0), max(int(cols.numel()), 1)))
+            self.cols.append(cols)
+            self.blocks.append(blk._coalesced_(True))       # still sorted by (row, column), no duplicates
+        counts = torch.tensor([c.numel() for c in self.cols], dtype=torch.long, device=dev)
+        every = [torch.empty_like(counts) for _ in range(P)]
+        dist.all_gather(every, counts, group=group)
+        self.K = torch.stack(every).cpu()                    # K[dst][src]
+        want = torch.cat([c.to(torch.int32) for c in self.cols]) if P > 1 else torch.zeros(0, dtype=torch.int32, device=dev)
+        in_split = [int(x) for x in self.K[rank]]
+        out_split = [int(x) for x in self.K[:, rank]]
+        got = torch.empty(sum(out_split), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(got, want, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        self.send_idx = list(got.split(out_split))
+        self.block_rows = adj_parts[0].size(1)
+        # the same number on every rank (K is): ranks must agree on whether this form is worth trying
+        self.fraction = float(self.K.sum()) / max(1, P * (P - 1) * self.block_rows)
+        self.local_fraction = float(self.K[rank].sum()) / max(1, (P - 1) * self.block_rows)
+
+    @staticmethod
+    def of(adj_parts, group):
+        nr = getattr(adj_parts, '_dgnn_needed', None)
+        if nr is None:
+            nr = NeededRows(adj_parts, group)
+            try:
+                adj_parts._dgnn_needed = nr
+            except AttributeError:                # a plain list: rebuilt per call (tests only)
+                pass
+        return nr
 
 
 def _csr_block(A):
@@ -62,8 +131,10 @@ class StagePipeline:
     mode 'allgather'  one all-gather of every rank's block (the P broadcasts of a layer pass
                       are together an all-gather; one collective keeps every xGMI link busy),
                       then the P SpMMs.
-    mode 'auto'       (default) the first time a (tag, shape) is aggregated, both forms are run
-                      and timed on the spot, the slower rank's time decides (all-reduce MAX, so
+    mode 'needed'     point-to-point: the owner of stage j sends every peer only the rows of H_j
+                      that peer's block references (NeededRows), pipelined like 'bcast'.
+    mode 'auto'       (default) the first time a (tag, shape) is aggregated, the forms are run
+                      and timed on the spot ('needed' joins when under 3/4 of the rows are needed), the slower rank's time decides (all-reduce MAX, so
                       every rank picks the same form), and the choice sticks. Costs three extra
                       aggregations in the first epoch; results do not depend on the choice.
     All accumulate src = 0..P-1 in order, so z is bit-identical in every mode.
@@ -83,13 +154,15 @@ class StagePipeline:
 
     def __init__(self, mode=None, inflight=None, cache_input=None):
         self.mode = mode or os.environ.get('DGNN_PIPELINE', 'auto')
-        if self.mode not in ('auto', 'bcast', 'allgather'):
-            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast or allgather')
+        if self.mode not in ('auto', 'bcast', 'allgather', 'needed'):
+            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather or needed')
         self.inflight = max(2, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))
         self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
         self._bufs = {}
         self._input_cache = {}         # tag -> (key of the source tensor, [block per src])
         self.transfers = 0             # blocks actually moved (tests / logs)
+        self.rows_moved = 0            # feature rows received by this rank ...
+        self.rows_full = 0             # ... and what whole blocks would have been
         self.choice = {}               # (tag, rows, width, group size) -> (form, {form: seconds}) picked by 'auto'
 
     def _buffers(self, shape, like, count, tag=''):
@@ -199,6 +272,68 @@ class StagePipeline:
                 spmm(adj_parts[blk], block, z)
         return z
 
+    def _run_needed(self, adj_parts, feat, stages, group, z):
+        env = DistEnv.env
+        rank, timer = env.rank, env.timer
+        nr = NeededRows.of(adj_parts, group)
+        n, F = len(stages), feat.size(1)
+        if feat.is_cuda and _gather_override is None:
+            ld = self._wire_width(feat)
+            ld = ld if ld != F else (F + 3) // 4 * 4          # the gather kernel writes float4s
+        else:
+            ld = F
+        K = nr.K
+        depth = min(self.inflight, max(n, 1))
+        kmax = max(1, int(K[rank].max()))
+        recv = self._buffers((kmax, ld), feat, depth, 'needed-recv')
+        out_rows = [int(K[dst][rank]) for dst in range(len(K))]
+        send = self._buffers((max(1, sum(out_rows)), ld), feat, 1, 'needed-send')[0]
+        pending, sends = {}, []
+
+        def post(i):
+            src = stages[i][0]
+            if src == rank:
+                ops, at = [], 0
+                for dst, k in enumerate(out_rows):
+                    if dst == rank or k == 0:
+                        continue
+                    part = send[at:at + k]
+                    at += k
+                    _gather_rows(feat, nr.send_idx[dst], part)
+                    ops.append(dist.P2POp(dist.isend, part, dst, group))
+                sends.extend(dist.batch_isend_irecv(ops) if ops else [])
+                pending[i] = ([], None)
+                return
+            k = int(K[rank][src])
+            if k == 0:
+                pending[i] = ([], None)
+                return
+            buf = recv[i % len(recv)][:k]
+            pending[i] = (dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, src, group)]), buf)
+            self.rows_moved += k
+
+        for i in range(min(depth - 1, n)):
+            post(i)
+        for i, (src, blk) in enumerate(stages):
+            if i + depth - 1 < n:
+                post(i + depth - 1)
+            works, buf = pending.pop(i)
+            with timer.timing_cuda('broadcast'):
+                for w in works:
+                    w.wait()
+            self.transfers += 1
+            if src == rank:
+                with timer.timing_cuda('spmm'):
+                    spmm(adj_parts[blk], feat, z)
+                continue
+            self.rows_full += nr.block_rows
+            if buf is not None:
+                with timer.timing_cuda('spmm'):
+                    spmm(nr.blocks[src], buf[:, :F] if ld != F else buf, z)
+        for w in sends:                       # the send buffer is reused by the next aggregation
+            w.wait()
+        return z
+
     def _pick_form(self, adj_parts, feat, stages, group, tag):
         """'auto': time both forms once for this (tag, shape) and keep the faster one."""
         key = (tag, feat.size(0), feat.size(1), len(stages))
@@ -208,6 +343,11 @@ class StagePipeline:
         import time
         sent = self.transfers
 
+        forms = ['bcast', 'allgather']
+        if self._needed_ok(adj_parts, stages, group) and NeededRows.of(adj_parts, group).fraction < 0.75:
+            forms.append('needed')
+        moved = (self.rows_moved, self.rows_full)
+
         def once(form):
             z = torch.zeros((adj_parts[stages[0][1]].size(0), feat.size(1)), dtype=feat.dtype, device=feat.device)
             if feat.is_cuda:
@@ -215,24 +355,33 @@ class StagePipeline:
             t0 = time.perf_counter()
             if form == 'bcast':
                 self._run_bcast(adj_parts, feat, stages, group, z, None, None)
-            else:
+            elif form == 'allgather':
                 self._run_allgather(adj_parts, feat, stages, group, z, None)
+            else:
+                self._run_needed(adj_parts, feat, stages, group, z)
             if feat.is_cuda:
                 torch.cuda.synchronize(feat.device)
             return time.perf_counter() - t0
 
         with torch.no_grad():
-            once('bcast')                                   # builds CSR blocks, plans and buffers: not timed
-            once('allgather')
-            t = torch.tensor([once('bcast'), once('allgather')], dtype=torch.float64, device=feat.device)
+            for f in forms:                                 # builds CSR blocks, plans and buffers: not timed
+                once(f)
+            t = torch.tensor([once(f) for f in forms], dtype=torch.float64, device=feat.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        tb, ta = (float(x) for x in t.tolist())
-        form = 'allgather' if ta < tb else 'bcast'
-        self.choice[key] = (form, {'bcast': tb, 'allgather': ta})
+        times = dict(zip(forms, (float(x) for x in t.tolist())))
+        form = min(forms, key=lambda f: (times[f], forms.index(f)))
+        self.choice[key] = (form, times)
+        self.rows_moved, self.rows_full = moved
         self.transfers = sent                               # tuning traffic is not part of the count
         DistEnv.env.logger.log(f'pipeline auto {tag} [{feat.size(0)}x{feat.size(1)}] P={len(stages)}: '
-                               f'bcast {tb * 1e3:.3f} ms, allgather {ta * 1e3:.3f} ms -> {form}', rank=0)
+                               + ', '.join(f'{f} {times[f] * 1e3:.3f} ms' for f in forms) + f' -> {form}', rank=0)
         return form
+
+    @staticmethod
+    def _needed_ok(adj_parts, stages, group):
+        env = DistEnv.env
+        return (len(stages) == env.world_size > 1 and dist.get_world_size(group) == env.world_size
+                and all(src == blk for src, blk in stages) and len(adj_parts) == env.world_size)
 
     def run(self, adj_parts, feat, tag, policy=None, group=None, stages=None):
         """z = sum over stages of A[stage.block] @ H_(stage.src).
@@ -271,7 +420,10 @@ class StagePipeline:
         can_gather = plain and len(stages) == dist.get_world_size(group) and len(stages) > 1
         if form == 'auto':
             form = self._pick_form(adj_parts, feat, stages, group, tag) if can_gather else 'bcast'
-        if form == 'allgather' and can_gather:
+        if form == 'needed' and plain and self._needed_ok(adj_parts, stages, group):
+            self._run_needed(adj_parts, feat, stages, group, z)
+            keep = None                                     # compact blocks are not kept: nothing to reuse
+        elif form == 'allgather' and can_gather:
             self._run_allgather(adj_parts, feat, stages, group, z, keep)
         else:
             self._run_bcast(adj_parts, feat, stages, group, z, keep, policy)
@@ -331,7 +483,9 @@ class DistGCNLayer(torch.autograd.Function):
         blocks = getattr(ctx.adj_parts, 'transposed', None) or ctx.adj_parts
         ag = broadcast(blocks, grad_output, 'Backward' + ctx.tag)
         with DistEnv.env.timer.timing_cuda('mm'):
-            grad_features = torch.mm(ag, weight.t())
+            # the input features of layer 1 need no gradient: skip that product (the reference computes
+            # and discards it, gcn.py:49); every gradient that is used is unchanged
+            grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
             grad_weight = torch.mm(features.t(), ag)
         with DistEnv.env.timer.timing_cuda('all_reduce'):
             DistEnv.env.all_reduce_sum(grad_weight)

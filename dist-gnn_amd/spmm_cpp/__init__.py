@@ -224,6 +224,31 @@ def pad_rows(src, dst=None):
     return dst
 
 
+_lib.dgnn_gather_rows_f32.argtypes = [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]
+_lib.dgnn_gather_rows_f32.restype = ctypes.c_int
+
+
+def gather_rows(src, idx, dst=None):
+    """dst[r] = src[idx[r]] packed at the padded pitch (zero fill): the rows of a feature block one peer
+    needs (1D_CAGNET/dist_1d.py:43 ``t[needed_rows_idx]``). ``idx`` int32 on the device, values in
+    [0, src.size(0)) -- the caller guarantees the range (it built the list from the adjacency block)."""
+    sptr, lds = _dense(src, 'src')
+    n, F = src.shape
+    _need(idx, torch.int32, 'idx', 1)
+    if idx.device != src.device:
+        raise RuntimeError('gather_rows: idx and src are on different devices')
+    idx = idx.contiguous()
+    k = idx.numel()
+    if dst is None:
+        dst = torch.empty(k, padded_width(F), dtype=torch.float32, device=src.device)
+    dptr, ldd = _dense(dst, 'dst')
+    if dst.size(0) < k or dst.size(1) < F:
+        raise RuntimeError('gather_rows: dst is too small')
+    with torch.cuda.device(src.device):
+        _check(_lib.dgnn_gather_rows_f32(sptr, lds, n, idx.data_ptr(), k, dptr, ldd, F, _stream(src)), 'gather_rows')
+    return dst
+
+
 def default_stage_count(n, m, nnz, F):
     """Column-block stages for a block (measured on MI355X, Reddit-shape sweeps in DESIGN.md):
     one stage while the padded B fits the Infinity Cache comfortably; otherwise enough stages that one

@@ -93,6 +93,16 @@ int dgnn_pad_rows_f32(const float* src, int64_t lds, float* dst, int64_t ldd,
                       int32_t n, int32_t F, void* stream);
 
 /*
+ * dst[r, 0:F] = src[idx[r], 0:F], dst[r, F:ldd] = 0 for r < k: packs the rows of a feature block that
+ * one peer's adjacency block references, already at the padded pitch dgnn_spmm_plan_f32 reads
+ * (ldd % 4 == 0, dst 16-byte aligned). idx[k] int32, each in [0, nsrc) -- NOT checked on the device.
+ * Replaces the advanced-indexing copy `t[needed_rows_idx]` of the needed-rows-only transfer
+ * (1D_CAGNET/dist_1d.py:33-50 p2p_broadcast, same in dist_15d.py:35-52).
+ */
+int dgnn_gather_rows_f32(const float* src, int64_t lds, int32_t nsrc, const int32_t* idx, int32_t k,
+                         float* dst, int64_t ldd, int32_t F, void* stream);
+
+/*
  * Work plan of one CSR block for dgnn_spmm_plan_f32 (built once per block; the host-side
  * builder is dist-gnn_amd/spmm_cpp: SegPlan). Integer data only.
  *

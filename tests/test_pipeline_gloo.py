@@ -26,6 +26,12 @@ def _oracle_spmm(A, B, C):
     ref_cpu.spmm_coo(idx[0], idx[1], A.values().numpy(), A.size(0), A.size(1), Bc, C.numpy(), 1.0, 1.0)
 
 
+def _cpu_gather(src, idx, dst):
+    dst.zero_()
+    dst[:, :src.size(1)] = src.detach()[idx.long()]
+    return dst
+
+
 def _worker(rank, world, port, name, mode, inflight, log_dir, q):
     try:
         for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
@@ -38,7 +44,7 @@ def _worker(rank, world, port, name, mode, inflight, log_dir, q):
         import dist_train
         import dist_utils
         from models import gcn, cached_gcn
-        gcn.set_spmm_backend(_oracle_spmm)
+        gcn.set_spmm_backend(_oracle_spmm, gather=_cpu_gather)
         env = dist_utils.DistEnv(rank, world, 'gloo', echo=False)
         gold = np.load(os.path.join(ROOT, 'tests', 'golden', f'{name}_graph.npz'))
         w = np.load(os.path.join(ROOT, 'tests', 'golden', f'{name}_P{world}.npz'))
@@ -76,6 +82,7 @@ def _worker(rank, world, port, name, mode, inflight, log_dir, q):
                                       np.abs(z2.numpy() - w[f'r{rank}_cached_z2']).max()))
         res['summary'] = env.timer.summary_all()
         res['pipeline'] = gcn.pipeline().describe()
+        res['rows'] = (gcn.pipeline().rows_moved, gcn.pipeline().rows_full)
         res['choices'] = {k: v[0] for k, v in gcn.pipeline().choice.items()}
         q.put((rank, res))
         env.barrier_all()
@@ -104,7 +111,8 @@ def _run(world, name, mode='bcast', inflight=2, tmp='/tmp'):
 @pytest.mark.parametrize('world,name,mode,inflight', [
     (2, 'tiny', 'bcast', 2), (3, 'tiny', 'bcast', 2), (3, 'ragged', 'bcast', 3), (2, 'ragged', 'allgather', 2),
     (2, 'directed', 'bcast', 2), (2, 'multilabel', 'bcast', 2), (1, 'tiny', 'bcast', 2),
-    (2, 'tiny', 'auto', 2), (3, 'ragged', 'auto', 2)])
+    (2, 'tiny', 'auto', 2), (3, 'ragged', 'auto', 2), (2, 'tiny', 'needed', 2), (3, 'ragged', 'needed', 3),
+    (2, 'directed', 'needed', 2)])
 def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
     out = _run(world, name, mode, inflight, str(tmp_path))
     for r, res in out.items():
@@ -112,6 +120,8 @@ def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
         assert res['out_err'] <= 1e-5 and res['gf_err'] <= 1e-5 and res['gw_err'] <= 1e-5, res
         assert res['cached_err'] <= 1e-6, res
         assert 'spmm' in res['summary'] and 'broadcast' in res['summary'] or world == 1
+        if mode == 'needed' and world > 1:
+            assert 0 < res['rows'][0] <= res['rows'][1], res['rows']
         if mode == 'auto':       # every rank settled on the same form for every (tag, shape) it tuned
             assert res['choices'] and res['choices'] == out[0]['choices'], (res['choices'], out[0]['choices'])
             assert set(res['choices'].values()) <= {'bcast', 'allgather'} and res['pipeline'].startswith('auto(')

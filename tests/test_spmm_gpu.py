@@ -253,3 +253,31 @@ def test_aggregate_helper_and_plan_errors():
         spmm_cpp.spmm_plan(blk, torch.rand(m, F + 1, device=dev)[:, 1:], Z)
     with pytest.raises(RuntimeError):
         spmm_cpp.spmm_plan(blk, torch.rand(m + 1, 128, device=dev), Z)
+
+
+@pytest.mark.parametrize('F,ldd', [(1, 4), (41, 44), (41, 64), (100, 128), (602, 608), (256, 256), (7, 32)])
+def test_gather_rows_is_an_exact_copy(F, ldd):
+    """dgnn_gather_rows_f32: packed rows (repeats and any order allowed), zero fill up to the pitch."""
+    import spmm_cpp
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(F * 7 + ldd)
+    n, k = 5000, 3777
+    src = torch.rand(n, F, generator=g).to(dev)
+    idx = torch.randint(0, n, (k,), generator=g).to(torch.int32).to(dev)
+    dst = torch.full((k, ldd), float('nan'), device=dev)
+    out = spmm_cpp.gather_rows(src, idx, dst)
+    assert out.data_ptr() == dst.data_ptr()
+    assert torch.equal(dst[:, :F], src[idx.long()])
+    assert torch.count_nonzero(dst[:, F:]) == 0 and not torch.isnan(dst).any()
+    # strided source (a padded block) and a freshly allocated destination
+    wide = torch.rand(n, F + 5, generator=g).to(dev)
+    got = spmm_cpp.gather_rows(wide[:, :F], idx)
+    assert got.shape == (k, spmm_cpp.padded_width(F)) and torch.equal(got[:, :F], wide[:, :F][idx.long()])
+    # nothing to gather: no launch, no error
+    spmm_cpp.gather_rows(src, idx[:0], dst[:0])
+    with pytest.raises(RuntimeError):
+        spmm_cpp.gather_rows(src.cpu(), idx, dst)
+    with pytest.raises(RuntimeError):
+        spmm_cpp.gather_rows(src, idx.long(), dst)
+    with pytest.raises(RuntimeError, match='overlap'):
+        spmm_cpp.gather_rows(dst, idx, dst)

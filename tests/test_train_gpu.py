@@ -120,3 +120,26 @@ def test_transfer_forms_over_rccl_world1(env, F):
     torch.cuda.synchronize()
     assert torch.equal(z1, want) and torch.equal(z2, want) and torch.equal(z3, want)
     assert pipe.transfers == 3
+
+
+@pytest.mark.parametrize('F', [602, 100, 41])
+def test_needed_rows_block_equals_whole_block(env, F):
+    """The needed-rows transfer on the device side: rows packed by dgnn_gather_rows_f32 and the block with
+    renumbered columns give the same bits as the whole block on the whole feature matrix."""
+    import spmm_cpp
+    from models import gcn
+    dev = env.device
+    g = torch.Generator().manual_seed(F + 1)
+    n, m = 2500, 4000
+    idx = torch.stack([torch.randint(0, n, (9000,), generator=g), torch.randint(0, m, (9000,), generator=g) // 3 * 3])
+    A = torch.sparse_coo_tensor(idx, torch.rand(9000, generator=g), (n, m)).coalesce().to(dev)
+    H = torch.rand(m, F, generator=g).to(dev)
+    want = torch.zeros(n, F, device=dev)
+    gcn.spmm(A, H, want)
+    cols, inv = torch.unique(A.indices()[1], sorted=True, return_inverse=True)
+    assert cols.numel() < 0.4 * m
+    compact = torch.sparse_coo_tensor(torch.stack([A.indices()[0], inv]), A.values(), (n, cols.numel()))._coalesced_(True)
+    packed = spmm_cpp.gather_rows(H, cols.to(torch.int32))
+    got = torch.zeros(n, F, device=dev)
+    gcn.spmm(compact, packed[:, :F], got)
+    assert torch.equal(got, want)

@@ -173,6 +173,45 @@ def scenario_transform_first(env, rank, world, gold_dir):
                 wide=g.features.size(1))
 
 
+def scenario_needed_rows(env, rank, world, gold_dir):
+    """A sparse random graph (most columns of a block empty): needed-rows transfer vs whole blocks."""
+    import coo_graph
+    from models import gcn
+    g0 = torch.Generator().manual_seed(11)
+    n, e = 301, 420
+    ei = torch.randint(0, n, (2, e), generator=g0)
+    raw = {"edge_index": ei, "features": torch.rand(n, 7, generator=g0), "labels": torch.randint(0, 3, (n,), generator=g0),
+           "train_mask": torch.ones(n, dtype=torch.bool), "val_mask": torch.zeros(n, dtype=torch.bool),
+           "test_mask": torch.zeros(n, dtype=torch.bool), "num_nodes": n, "num_edges": e, "num_classes": 3}
+    full = coo_graph.COO_Graph('sparse', attr_dict=raw)
+    g = coo_graph.Parted_COO_Graph('sparse', rank, world, attr_dict=full.partition(world, save=False, with_transpose=True)[rank],
+                                   transposed_backward=True)
+    res = {}
+    for mode in ('bcast', 'needed', 'auto'):
+        gcn._pipeline = gcn.StagePipeline(mode=mode, cache_input=False)
+        z = gcn.broadcast(g.adj_parts, g.features, 'ForwardL1')
+        X = g.features.clone().requires_grad_(True)
+        W = torch.ones(7, 4, requires_grad=True)
+        y = gcn.DistGCNLayer.apply(X, W, g.adj_parts, 'L2')
+        y.sum().backward()
+        pipe = gcn.pipeline()
+        res[mode] = dict(z=z.clone(), dx=X.grad.clone(), dw=W.grad.clone(), rows=(pipe.rows_moved, pipe.rows_full),
+                         forms=sorted({f for v in pipe.choice.values() for f in v[1]}), transfers=pipe.transfers)
+    nr = gcn.NeededRows.of(g.adj_parts, env.world_group)
+    out = dict(fraction=nr.fraction, rows=res['needed']['rows'], auto_forms=res['auto']['forms'],
+               transfers=[res[m]['transfers'] for m in ('bcast', 'needed', 'auto')])
+    for mode in ('needed', 'auto'):
+        out[mode] = all(torch.equal(res[mode][k], res['bcast'][k]) for k in ('z', 'dx', 'dw'))
+    gcn._pipeline = None
+    return out
+
+
+def _cpu_gather(src, idx, dst):
+    dst.zero_()
+    dst[:, :src.size(1)] = src.detach()[idx.long()]
+    return dst
+
+
 def _worker(rank, world, port, scenario, log_dir, q):
     try:
         for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
@@ -182,7 +221,7 @@ def _worker(rank, world, port, scenario, log_dir, q):
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DGNN_LOG_DIR=log_dir)
         import dist_utils
         from models import gcn
-        gcn.set_spmm_backend(_oracle_spmm)
+        gcn.set_spmm_backend(_oracle_spmm, gather=_cpu_gather)
         env = dist_utils.DistEnv(rank, world, 'gloo', echo=False)
         res = globals()['scenario_' + scenario](env, rank, world, os.path.join(ROOT, 'tests', 'golden'))
         q.put((rank, res))
@@ -250,6 +289,15 @@ def test_transform_first_is_the_same_layer(tmp_path):
         assert res['wide'] > 5
         assert 0 < res['out'] <= 1e-5, res            # re-associated (not bit-equal), within the 1e-5 bar
         assert res['dx'] == 0.0 and res['dw'] == 0.0, res
+
+
+def test_needed_rows_transfer_is_bit_identical(tmp_path):
+    out = _run(3, 'needed_rows', str(tmp_path))
+    for r, res in out.items():
+        assert res['needed'] and res['auto'], res             # same bits as whole-block broadcasts, fwd and bwd
+        assert res['fraction'] < 0.75 and res['rows'][0] < 0.75 * res['rows'][1], res
+        assert res['auto_forms'] == ['allgather', 'bcast', 'needed']
+        assert res['transfers'][0] == res['transfers'][1] == res['transfers'][2]
 
 
 def test_input_cache_is_lossless(tmp_path):

@@ -60,19 +60,36 @@ def sparse_2d_split(st, split_size, split_dim=0):
 
     Returns a list of coalesced sparse tensors; slab k keeps the entries whose index along
     split_dim lies in [k*split_size, (k+1)*split_size), re-based to start at 0.
+
+    One pass instead of the reference's mask per slab (graph_utils.py:46-54): a coalesced COO is
+    sorted by (row, column), so row slabs are contiguous ranges (a binary search finds the cuts) and
+    column slabs come out of ONE stable sort by slab number, which keeps the (row, column) order
+    inside every slab -- exactly the order coalesce() would give, so the blocks are bit-identical.
     """
     if not st.is_coalesced():
         st = st.coalesce()
     idx, val = st.indices(), st.values()
     extent = st.size(split_dim)
     along, other = idx[split_dim], idx[1 - split_dim]
+    nslab = (extent + split_size - 1) // split_size if extent > 0 else 0
+    if nslab == 0:
+        return []
+    edges = torch.arange(0, nslab + 1, dtype=along.dtype, device=along.device) * split_size
+    if split_dim == 0:
+        cuts = torch.searchsorted(along.contiguous(), edges).tolist()
+        order = None
+    else:
+        slab = along // split_size
+        order = torch.argsort(slab, stable=True)
+        cuts = torch.searchsorted(slab[order].contiguous(), torch.arange(0, nslab + 1, dtype=along.dtype, device=along.device)).tolist()
+        along, other, val = along[order], other[order], val[order]
     parts = []
-    for lower in range(0, extent, split_size):
-        upper = min(lower + split_size, extent)
-        keep = (along >= lower) & (along < upper)
-        moved = along[keep] - lower
+    for k in range(nslab):
+        lower, upper = k * split_size, min((k + 1) * split_size, extent)
+        lo, hi = cuts[k], cuts[k + 1]
+        moved = along[lo:hi] - lower
         if split_dim == 0:
-            parts.append(_coalesced(torch.stack([moved, other[keep]]), val[keep], (upper - lower, st.size(1))))
+            parts.append(_coalesced(torch.stack([moved, other[lo:hi]]), val[lo:hi].clone(), (upper - lower, st.size(1))))
         else:
-            parts.append(_coalesced(torch.stack([other[keep], moved]), val[keep], (st.size(0), upper - lower)))
+            parts.append(_coalesced(torch.stack([other[lo:hi], moved]), val[lo:hi].clone(), (st.size(0), upper - lower)))
     return parts

@@ -86,11 +86,33 @@ class BlockList(list):
     transposed = None
 
 
-def partition_dict(attr_dict, num_parts, padding=True, with_transpose=False):
+def csr_arrays(block):
+    """int32 CSR (rowptr[n+1], col[nnz]) + values of a coalesced COO block, with torch integer ops so the
+    offline partitioner can run on the CPU. Same arrays as dgnn_coo2csr_i32 / dgnn_idx_i64_to_i32 build
+    on the device at first use (checked bit-exact in tests/test_host_golden.py)."""
+    idx, n = block.indices(), block.size(0)
+    if max(block.shape) >= 2 ** 31 or idx.size(1) >= 2 ** 31:
+        raise ValueError('block too large for int32 CSR')
+    rowptr = torch.zeros(n + 1, dtype=torch.long, device=idx.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(idx[0], minlength=n), 0)
+    return rowptr.to(torch.int32), idx[1].to(torch.int32), block.values().clone()
+
+
+def _add_csr(d, key, slab, split_size):
+    for j, blk in enumerate(graph_utils.sparse_2d_split(slab, split_size, split_dim=1)):
+        rp, col, val = csr_arrays(blk)
+        d[f'{key}{j}__rowptr'], d[f'{key}{j}__col'], d[f'{key}{j}__val'] = rp, col, val
+        d[f'{key}{j}__shape'] = torch.tensor(list(blk.shape))
+
+
+def partition_dict(attr_dict, num_parts, padding=True, with_transpose=False, with_csr=False):
     """The arithmetic of COO_Graph.partition (parted_coo_graph.py:63-93) on an in-memory dict:
     returns (split_size, [per-rank attr dict]). ``with_transpose`` also stores the row slab of A^T
     per rank ('adj_t') -- the role of the older partitioner's pre-transposed column slabs
-    (1D_CAGNET/dist_data.py:59-63,84-108)."""
+    (1D_CAGNET/dist_data.py:59-63,84-108). ``with_csr`` stores, next to the COO slab,
+    the int32 CSR of every column block A[rank, j] ('csr{j}__rowptr/col/val', and 'csrt{j}__*' for the
+    transposed blocks), so loading a part needs no index conversion at all -- the reference converts
+    int64 -> int32 twice per SpMM call (gcn.py:11)."""
     n = attr_dict['num_nodes']
     adj, feats = attr_dict['adj'], attr_dict['features']
     split_size = (n + num_parts - 1) // num_parts
@@ -125,6 +147,10 @@ def partition_dict(attr_dict, num_parts, padding=True, with_transpose=False):
         d['adj'], d['features'] = adj_rows[i], feat_rows[i]
         if adj_t_rows is not None and i < len(adj_t_rows):
             d['adj_t'] = adj_t_rows[i]
+        if with_csr:
+            _add_csr(d, 'csr', adj_rows[i], split_size)
+            if 'adj_t' in d:
+                _add_csr(d, 'csrt', d['adj_t'], split_size)
         parts.append(d)
     return split_size, parts
 
@@ -145,10 +171,10 @@ class COO_Graph(BasicGraph):
                 GraphCache.save_dict(cached, self.cache_path)
         super().__init__(cached, name, device)
 
-    def partition(self, num_parts, padding=True, save=True, with_transpose=False):
+    def partition(self, num_parts, padding=True, save=True, with_transpose=False, with_csr=False):
         d = dict(self.attr_dict)
         d.update(adj=self.adj, features=self.features)
-        _, parts = partition_dict(d, num_parts, padding, with_transpose)
+        _, parts = partition_dict(d, num_parts, padding, with_transpose, with_csr)
         if save:
             for i, part in enumerate(parts):
                 GraphCache.save_dict(part, GraphCache.parted_graph_path(self.name, self.preprocess_for, i, num_parts))
@@ -176,6 +202,23 @@ class Parted_COO_Graph(BasicGraph):
                 raise Exception('transposed_backward needs part files written with partition(..., with_transpose=True)')
             self.adj_parts.transposed = graph_utils.sparse_2d_split(attr_dict['adj_t'].to(device), self.local_num_nodes,
                                                                     split_dim=1)
+        self.csr_from_file = self._attach_csr(attr_dict, 'csr', self.adj_parts)
+        if self.adj_parts.transposed is not None:
+            self._attach_csr(attr_dict, 'csrt', self.adj_parts.transposed)
+
+    def _attach_csr(self, attr_dict, key, blocks):
+        """Part files written with partition(..., with_csr=True): hand the stored int32 CSR of every block
+        to the SpMM operator (spmm_cpp.CsrBlock) so nothing is converted at the first call. GPU only."""
+        if f'{key}0__rowptr' not in attr_dict or torch.device(self.device).type != 'cuda':
+            return False
+        import spmm_cpp
+        for j, blk in enumerate(blocks):
+            shape = tuple(int(x) for x in attr_dict[f'{key}{j}__shape'])
+            if shape != tuple(blk.shape):
+                raise Exception(f'part file: stored CSR block {j} has shape {shape}, the COO block {tuple(blk.shape)}')
+            blk._dgnn_csr = spmm_cpp.CsrBlock(shape[0], shape[1], *(attr_dict[f'{key}{j}__{a}'].to(self.device).contiguous()
+                                                                   for a in ('rowptr', 'col', 'val')))
+        return True
 
     def __repr__(self):
         return super().__repr__() + f'<Local: {self.rank}, |V|: {self.local_num_nodes}, |E|: {self.local_num_edges}>'

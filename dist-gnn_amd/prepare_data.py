@@ -10,10 +10,12 @@ def main(argv=None):
     ap.add_argument('--dataset', default='cora')
     ap.add_argument('--parts', type=int, nargs='+', default=[4, 8])
     ap.add_argument('--no-cache', action='store_true')
+    ap.add_argument('--no-csr', action='store_true', help='do not store the int32 CSR blocks in the part files')
+    ap.add_argument('--transpose', action='store_true', help='also store the blocks of A^T (exact backward on directed graphs)')
     args = ap.parse_args(argv)
     g = coo_graph.COO_Graph(args.dataset, full_graph_cache_enabled=not args.no_cache)
     for p in args.parts:
-        g.partition(p)
+        g.partition(p, with_csr=not args.no_csr, with_transpose=args.transpose)
         print(coo_graph.Parted_COO_Graph(args.dataset, 0, p))
     print(g)
 

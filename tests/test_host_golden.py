@@ -68,6 +68,36 @@ def test_partition_and_local_view(golden_dir, name, P, tmp_path, monkeypatch):
             assert pg.local_num_nodes == pg.adj.size(0) and pg.local_num_edges == pg.adj._nnz()
 
 
+@pytest.mark.parametrize('name,P', [('tiny', 2), ('ragged', 3), ('directed', 2)])
+def test_part_files_carry_int32_csr_blocks(golden_dir, name, P, tmp_path, monkeypatch):
+    """partition(..., with_csr=True): the stored CSR of every block equals the oracle's coo2csr of the
+    reference's block (tests/golden), through the cache file and back (weights_only load)."""
+    import coo_graph
+    from coo_graph import datasets, parted_coo_graph
+    from oracle import ref_cpu
+    monkeypatch.setattr(datasets, 'data_root', str(tmp_path))
+    g = np.load(os.path.join(golden_dir, f'{name}_graph.npz'))
+    w = np.load(os.path.join(golden_dir, f'{name}_P{P}.npz'))
+    full = coo_graph.COO_Graph(name, attr_dict=_raw(g))
+    full.partition(P, with_csr=True, with_transpose=True)
+    for r in range(P):
+        d = parted_coo_graph.GraphCache.load_dict(parted_coo_graph.GraphCache.parted_graph_path(name, 'GCN', r, P))
+        pg = coo_graph.Parted_COO_Graph(name, r, P, attr_dict=d, transposed_backward=True)
+        assert pg.csr_from_file is False                      # CPU: arrays are read, nothing is attached
+        for j in range(P):
+            idx = w[f'r{r}_adj_part{j}_idx']
+            n = int(w[f'r{r}_adj_part{j}_shape'][0])
+            assert d[f'csr{j}__rowptr'].dtype == torch.int32 and d[f'csr{j}__col'].dtype == torch.int32
+            assert np.array_equal(d[f'csr{j}__rowptr'].numpy(), ref_cpu.coo2csr(idx[0].astype(np.int32), n))
+            assert np.array_equal(d[f'csr{j}__col'].numpy(), idx[1].astype(np.int32))
+            np.testing.assert_allclose(d[f'csr{j}__val'].numpy(), w[f'r{r}_adj_part{j}_val'], rtol=1e-6)
+            assert tuple(d[f'csr{j}__shape'].tolist()) == tuple(w[f'r{r}_adj_part{j}_shape'])
+            t = pg.adj_parts.transposed[j].coalesce()         # the transposed blocks carry theirs too
+            assert np.array_equal(d[f'csrt{j}__col'].numpy(), t.indices()[1].numpy().astype(np.int32))
+            assert np.array_equal(d[f'csrt{j}__rowptr'].numpy(),
+                                  ref_cpu.coo2csr(t.indices()[0].numpy().astype(np.int32), t.size(0)))
+
+
 def test_synthetic_dataset_schema_and_determinism():
     from coo_graph import synthetic, datasets
     a = synthetic.make_dataset('cora', seed=3)

@@ -143,3 +143,27 @@ def test_needed_rows_block_equals_whole_block(env, F):
     got = torch.zeros(n, F, device=dev)
     gcn.spmm(compact, packed[:, :F], got)
     assert torch.equal(got, want)
+
+
+def test_csr_blocks_from_the_part_file_are_used(env, golden_dir, tmp_path, monkeypatch):
+    """Part files written with with_csr=True: the loader hands the stored int32 CSR to the operator, no
+    COO -> CSR conversion runs, and the stage loop still reproduces the reference's z bit for bit."""
+    import coo_graph
+    import spmm_cpp
+    from coo_graph import datasets
+    from models import gcn
+    monkeypatch.setattr(datasets, 'data_root', str(tmp_path))
+    g = np.load(os.path.join(golden_dir, 'ragged_graph.npz'))
+    w = np.load(os.path.join(golden_dir, 'ragged_P3.npz'))
+    full = coo_graph.COO_Graph('ragged', attr_dict=_raw(g, 'cpu'))
+    full.partition(3, with_csr=True)
+    monkeypatch.setattr(spmm_cpp.CsrBlock, 'from_coo', classmethod(lambda cls, A: pytest.fail('converted at run time')))
+    dev = env.device
+    feats = [torch.from_numpy(w[f'r{r}_features']).to(dev) for r in range(3)]
+    for r in range(3):
+        pg = coo_graph.Parted_COO_Graph('ragged', r, 3, device=dev)
+        assert pg.csr_from_file
+        z = torch.zeros_like(feats[r])
+        for src in range(3):
+            gcn.spmm(pg.adj_parts[src], feats[src], z)
+        assert np.array_equal(z.cpu().numpy(), w[f'r{r}_layer_z'])

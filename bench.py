@@ -106,11 +106,17 @@ def main():
     ap.add_argument('--model', default='GCN', choices=['GCN', 'CachedGCN'])
     ap.add_argument('--cache-input', action='store_true',
                     help='reuse the layer-1 input-feature blocks received in the first epoch (lossless; off for the headline number)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="gloo = rehearsal of the N > 1 path on fewer GPUs than ranks (ranks share a GPU, blocks "
+                         "travel through host memory): checks the flow, the number is not a result")
     ap.add_argument('--transform-first', action='store_true',
                     help='opt-in A_hat (H W) ordering for layers with F_out < F_in (re-associated fp32; not the headline)')
     args = ap.parse_args()
     layers = args.layers or {'reddit': 2, 'products': 3, 'cora': 2}[args.workload]
 
+    if os.environ.get('DGNN_FAULT_TIMEOUT'):       # debugging aid: dump every thread's stack and exit if stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['DGNN_FAULT_TIMEOUT']), exit=True)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     rank = int(os.environ.get('RANK', 0))
@@ -128,7 +134,9 @@ def main():
     import dist_train
     import spmm_cpp
     from models import gcn as gcn_mod
-    env = dist_utils.DistEnv(rank, world, 'nccl', echo=False)
+    if args.backend == 'gloo':
+        os.environ['DGNN_GLOO_CUDA'] = '1'
+    env = dist_utils.DistEnv(rank, world, args.backend, echo=False)
     dev = env.device
 
     t_build = time.time()
@@ -207,7 +215,7 @@ def main():
             "data": f"synthetic (seeded R-MAT, {args.workload} shape, random-init torch.rand weights)",
             "config": {"workload": f"{args.workload}-shape {layers}-layer GCN, hidden {args.hidden}, 1D row partition over {world} GPU(s)",
                        "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
-                       "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transform_first": bool(args.transform_first),
+                       "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),
                        "scale": args.scale},
             "roofline": roofline, "cpu_baseline": cpu,
             "final_loss": round(loss_val, 4), "setup_s": round(t_build, 1),

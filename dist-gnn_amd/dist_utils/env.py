@@ -6,7 +6,9 @@ logger, timer, store and the ``DistEnv.env`` singleton -- with these deliberate 
 
   * device: the reference uses the GPU only when more than one is visible (env.py:26-31), so a
     1-GPU box silently trains on the CPU. Here a 'nccl' backend (or any visible GPU with a
-    non-gloo backend) selects ``cuda:LOCAL_RANK``; 'gloo' selects the CPU.
+    non-gloo backend) selects ``cuda:LOCAL_RANK``; 'gloo' selects the CPU, unless DGNN_GLOO_CUDA=1
+    (rehearsal: several ranks share the visible GPUs, the HIP kernels run, and the blocks travel
+    through gloo's host staging -- how the N > 1 path is exercised on a one-GPU box).
   * the P(P-1)/2 two-rank groups (env.py:50-54) are created lazily on first use: the GCN path
     never touches them and each costs an RCCL communicator.
   * an already-initialised default process group (torchrun) is reused.
@@ -51,7 +53,8 @@ class DistEnv:
         return '<DistEnv %d/%d %s>' % (self.rank, self.world_size, self.backend)
 
     def init_device(self):
-        if self.backend != 'gloo' and torch.cuda.is_available():
+        on_gpu = self.backend != 'gloo' or os.environ.get('DGNN_GLOO_CUDA', '0') == '1'
+        if on_gpu and torch.cuda.is_available():
             local = int(os.environ.get('LOCAL_RANK', self.rank)) % max(torch.cuda.device_count(), 1)
             self.device = torch.device('cuda', local)
             torch.cuda.set_device(self.device)
@@ -61,7 +64,7 @@ class DistEnv:
     def init_dist_groups(self):
         if not dist.is_initialized():
             kwargs = {}
-            if self.device.type == 'cuda':
+            if self.device.type == 'cuda' and self.backend != 'gloo':
                 kwargs['device_id'] = self.device
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size,
                                     init_method='env://', **kwargs)

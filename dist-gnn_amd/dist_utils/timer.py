@@ -36,7 +36,12 @@ class TimerCtx:
         if self.cuda and not self.sync:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
-            self.timer.pending[self.key].append((self.ev0, ev1))
+            pairs = self.timer.pending[self.key]
+            pairs.append((self.ev0, ev1))
+            if len(pairs) > 1024:                 # long runs: fold the finished pairs, without synchronising
+                flags = [p[1].query() for p in pairs]
+                self.timer.duration_dict[self.key] += sum(p[0].elapsed_time(p[1]) for p, f in zip(pairs, flags) if f) / 1e3
+                pairs[:] = [p for p, f in zip(pairs, flags) if not f]
         else:
             if self.sync:
                 torch.cuda.synchronize()

@@ -36,6 +36,13 @@ def set_spmm_backend(fn, gather=None):
     _gather_override = gather
 
 
+def _trace(*a):
+    if os.environ.get('DGNN_TRACE') == '1':
+        import sys
+        import time
+        print(f'[dgnn {time.perf_counter():.3f}]', *a, file=sys.stderr, flush=True)
+
+
 def _gather_rows(src, idx, dst):
     """dst[r, :F] = src[idx[r]] (dst may be wider: zero fill) with the HIP kernel dgnn_gather_rows_f32."""
     if _gather_override is not None:
@@ -156,7 +163,7 @@ class StagePipeline:
         self.mode = mode or os.environ.get('DGNN_PIPELINE', 'auto')
         if self.mode not in ('auto', 'bcast', 'allgather', 'needed'):
             raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather or needed')
-        self.inflight = max(2, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))
+        self.inflight = max(1, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))   # 1 = no overlap (debugging)
         self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
         self._bufs = {}
         self._input_cache = {}         # tag -> (key of the source tensor, [block per src])
@@ -261,9 +268,11 @@ class StagePipeline:
             if i + depth - 1 < n:
                 post(i + depth - 1)
             work, block = pending.pop(i)
+            _trace('bcast wait', rank, 'stage', i, 'src', src)
             with timer.timing_cuda('broadcast'):
                 if work is not None:
                     work.wait()
+            _trace('bcast got', rank, 'stage', i)
             if policy is not None and work is not None:
                 policy.arrived(src, block)
             if keep is not None and src != rank:
@@ -366,7 +375,9 @@ class StagePipeline:
         with torch.no_grad():
             for f in forms:                                 # builds CSR blocks, plans and buffers: not timed
                 once(f)
-            t = torch.tensor([once(f) for f in forms], dtype=torch.float64, device=feat.device)
+            # the vote travels as a host tensor under gloo (its CUDA path stages through the host anyway)
+            vote_dev = feat.device if dist.get_backend(group) == 'nccl' else 'cpu'
+            t = torch.tensor([once(f) for f in forms], dtype=torch.float64, device=vote_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         times = dict(zip(forms, (float(x) for x in t.tolist())))
         form = min(forms, key=lambda f: (times[f], forms.index(f)))
@@ -396,7 +407,11 @@ class StagePipeline:
         group = env.world_group if group is None else group
         if stages is None:
             stages = [(j, j) for j in range(env.world_size)]
-        feat = feat.contiguous()
+        orig = feat.contiguous()
+        # Collectives run on a view with its own version counter: a rooted broadcast "writes" its buffer on
+        # the root too as far as autograd can tell (gloo's CUDA path really does), and this tensor is often
+        # saved for backward (a ReLU output). Its bits are never changed here.
+        feat = orig.data
         z = torch.zeros((adj_parts[stages[0][1]].size(0) if stages else feat.size(0), feat.size(1)),
                         dtype=feat.dtype, device=feat.device)
         plain = policy is None
@@ -406,16 +421,17 @@ class StagePipeline:
             return z
 
         cacheable = (plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1')
-                     and not feat.requires_grad)
+                     and not orig.requires_grad)
         if cacheable:
             hit = self._input_cache.get(tag)
-            if hit is not None and hit[0] == self._tensor_key(feat):
+            if hit is not None and hit[0] == self._tensor_key(orig):
                 for src, blk in stages:
                     with timer.timing_cuda('spmm'):
                         spmm(adj_parts[blk], feat if src == rank else hit[1][src], z)
                 return z
         keep = {} if cacheable else None
 
+        _trace('run', rank, tag, tuple(feat.shape), self.mode)
         form = self.mode
         can_gather = plain and len(stages) == dist.get_world_size(group) and len(stages) > 1
         if form == 'auto':
@@ -428,7 +444,7 @@ class StagePipeline:
         else:
             self._run_bcast(adj_parts, feat, stages, group, z, keep, policy)
         if keep is not None:
-            self._input_cache[tag] = (self._tensor_key(feat), keep)
+            self._input_cache[tag] = (self._tensor_key(orig), keep)
         return z
 
 

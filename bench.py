@@ -57,10 +57,22 @@ def build_rank_graph(args, env):
     return g, n, nnz_total
 
 
+def host_threads():
+    """Threads for the CPU baseline: the box's CPU share (OMP_NUM_THREADS is set to it there), else the
+    cores this process may run on."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    want = int(os.environ.get('OMP_NUM_THREADS', 0) or 0)
+    return max(1, min(avail, want) if want > 0 else avail)
+
+
 def cpu_baseline(g, widths, budget_s, rank_rows):
     """Time the CPU oracle on the first `rows` rows of this rank's block (all column blocks = whole rows
-    of A_hat for P = 1), one thread, for each SpMM width of an epoch. Returns GEdges/s."""
+    of A_hat for P = 1), rows dealt to the host threads, for each SpMM width of an epoch. Returns GEdges/s."""
     from oracle import ref_cpu
+    threads = host_threads()
     adj = g.adj.coalesce()
     idx = adj.indices()
     row = idx[0]
@@ -69,7 +81,7 @@ def cpu_baseline(g, widths, budget_s, rank_rows):
     rp = torch.zeros(n_rows + 1, dtype=torch.long, device=row.device)
     rp[1:] = torch.cumsum(torch.bincount(row, minlength=n_rows), 0)
     per_nnz_fma = float(sum(widths))
-    target_nnz = int(budget_s * 1.5e9 / per_nnz_fma)
+    target_nnz = int(budget_s * 1.5e9 * max(1.0, threads * 0.5) / per_nnz_fma)
     r1 = int(torch.searchsorted(rp, torch.tensor([target_nnz], device=rp.device)).item())
     r1 = max(1, min(r1, n_rows))
     k1 = int(rp[r1].item())
@@ -83,12 +95,13 @@ def cpu_baseline(g, widths, budget_s, rank_rows):
         B = rng.random((m, F), dtype=np.float32)
         C = np.zeros((r1, F), dtype=np.float32)
         t0 = time.perf_counter()
-        ref_cpu.spmm_csr(rowptr, col, val, B, C, 1.0, 1.0)
+        ref_cpu.spmm_csr(rowptr, col, val, B, C, 1.0, 1.0, threads=threads)
         total_t += time.perf_counter() - t0
-    return dict(value=round(len(widths) * k1 / total_t / 1e9, 4), unit='GEdges/s', cores=1, kind='port',
-                sample=f'oracle/spmm_ref.c (ATen CPU sparse addmm chain, fmaf) on the first {r1} rows '
+    return dict(value=round(len(widths) * k1 / total_t / 1e9, 4), unit='GEdges/s', cores=threads, kind='port',
+                sample=f'oracle/spmm_ref.c (ATen CPU sparse addmm chain, fmaf; rows dealt to {threads} OpenMP '
+                       f'threads, same bits as one thread) on the first {r1} rows '
                        f'({k1} nonzeros) of the same normalised graph, SpMM widths {list(widths)} of one epoch, '
-                       f'B [{m} x F] fp32, single thread, {total_t:.1f} s; dense X.W, loss and Adam excluded',
+                       f'B [{m} x F] fp32, {total_t:.1f} s; dense X.W, loss and Adam excluded',
                 host_cpus=os.cpu_count())
 
 
@@ -155,6 +168,10 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    env.timer.resolve()
+    before = dict(env.timer.duration_dict)
+    pipe = gcn_mod.pipeline()
+    rows0 = (pipe.rows_moved, pipe.rows_full)
     spmm_cpp.prof_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -164,6 +181,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = spmm_cpp.prof_end()
+    env.timer.resolve()
+    # GPU time per step under the reference's timer keys (HIP events on the compute stream; 'broadcast' is
+    # the time the compute stream sat waiting for a feature block = exposed communication)
+    breakdown = {k: round((env.timer.duration_dict[k] - before.get(k, 0.0)) / args.steps * 1e3, 3)
+                 for k in ('broadcast', 'spmm', 'mm', 'all_reduce') if k in env.timer.duration_dict}
     loss_val = float(loss.item())
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -201,6 +223,14 @@ def main():
                     spmm_kernel_gedges_per_s=round(len(widths) * local_nnz * args.steps / stage_s / 1e9, 3) if stage_s > 0 else None,
                     gather_tb_per_s=round(sum(4 * F for F in widths) * local_nnz * args.steps / stage_s / 1e12, 3) if stage_s > 0 else None)
 
+    comm = None
+    if world > 1:
+        wire = sum(4 * s * gcn_mod.StagePipeline._wire_width(torch.empty(1, F, device=dev)) for F in widths) * (world - 1)
+        exposed = breakdown.get('broadcast', 0.0)
+        moved, full = pipe.rows_moved - rows0[0], pipe.rows_full - rows0[1]
+        comm = dict(form=pipe.describe(), recv_bytes_per_rank_per_step=int(wire), exposed_ms_per_step=exposed,
+                    recv_GBps_if_fully_exposed=round(wire / max(exposed, 1e-6) / 1e6, 1),
+                    xgmi_link_peak_GBps=153.0, needed_rows_fraction=(round(moved / full, 4) if full else None))
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         cpu = cpu_baseline(g, widths, args.cpu_budget, s)
@@ -217,7 +247,7 @@ def main():
                        "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
                        "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),
                        "scale": args.scale},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "gpu_ms_per_step": breakdown, "comm": comm,
             "final_loss": round(loss_val, 4), "setup_s": round(t_build, 1),
         }
         print(json.dumps(out), flush=True)

@@ -62,11 +62,17 @@ def spmm_coo(row, col, val, n, m, B, C, alpha=1.0, beta=1.0):
     return C
 
 
-def spmm_csr(rowptr, col, val, B, C, alpha=1.0, beta=1.0, r0=0, r1=None):
+def spmm_csr(rowptr, col, val, B, C, alpha=1.0, beta=1.0, r0=0, r1=None, threads=1):
+    """C = alpha*A@B + beta*C over rows [r0, r1). threads > 1: rows dealt to OpenMP threads, same bits."""
     rowptr, col, val = _i32c(rowptr), _i32c(col), _f32c(val)
     assert B.dtype == np.float32 and C.dtype == np.float32 and B.flags.c_contiguous and C.flags.c_contiguous
     F = C.shape[1]
     r1 = C.shape[0] if r1 is None else r1
+    if threads > 1:
+        lib().oracle_spmm_csr_f32_mt(_ptr(rowptr), _ptr(col), _ptr(val), ctypes.c_int32(r0), ctypes.c_int32(r1),
+                                     _ptr(B), ctypes.c_int64(F), _ptr(C), ctypes.c_int64(F), ctypes.c_int32(F),
+                                     ctypes.c_float(alpha), ctypes.c_float(beta), ctypes.c_int32(threads))
+        return C
     lib().oracle_spmm_csr_f32(_ptr(rowptr), _ptr(col), _ptr(val), ctypes.c_int32(r0), ctypes.c_int32(r1),
                               _ptr(B), ctypes.c_int64(F), _ptr(C), ctypes.c_int64(F), ctypes.c_int32(F),
                               ctypes.c_float(alpha), ctypes.c_float(beta))

@@ -76,6 +76,18 @@ void oracle_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float*
   }
 }
 
+/* The same per-row chain with the rows dealt to `threads` host threads (OpenMP). Rows are independent,
+ * so the result is bit-identical to oracle_spmm_csr_f32; this is the multi-core CPU baseline that
+ * bench.py times (the reference's CPU path is ATen's addmm_ under torch.set_num_threads). */
+void oracle_spmm_csr_f32_mt(const int32_t* rowptr, const int32_t* col, const float* val,
+                            int32_t r0, int32_t r1, const float* B, int64_t ldb, float* C, int64_t ldc,
+                            int32_t F, float alpha, float beta, int32_t threads) {
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+  for (int32_t i = r0; i < r1; ++i)
+    oracle_spmm_csr_f32(rowptr, col, val, i, i + 1, B, ldb, C, ldc, F, alpha, beta);
+}
+
 /* fp64 accumulation of the same sum and of sum|a*b| -- gives the tests an error yardstick:
  * |fp32 result - exact| <= gamma_n * abs_sum. */
 void oracle_spmm_csr_f64(const int32_t* rowptr, const int32_t* col, const float* val,

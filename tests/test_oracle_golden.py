@@ -106,3 +106,21 @@ def test_coo2csr_and_edge_cases():
     ref_cpu.spmm_coo(np.array([0], dtype=np.int32), np.array([1], dtype=np.int32), np.array([2.0], dtype=np.float32),
                      2, 2, np.arange(6, dtype=np.float32).reshape(2, 3), C, 1.0, 0.0)
     assert np.array_equal(C, [[6, 8, 10], [0, 0, 0]])
+
+
+def test_threaded_oracle_is_bit_identical():
+    """The multi-core CPU baseline (rows dealt to OpenMP threads) keeps the sequential chain per row."""
+    from oracle import ref_cpu
+    rng = np.random.default_rng(5)
+    n, m, F = 700, 500, 37
+    deg = rng.integers(0, 40, n)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(m, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.random(rowptr[-1], dtype=np.float32)
+    B = rng.random((m, F), dtype=np.float32)
+    C0 = rng.random((n, F), dtype=np.float32)
+    one = ref_cpu.spmm_csr(rowptr, col, val, B, C0.copy(), 0.5, 2.0)
+    many = ref_cpu.spmm_csr(rowptr, col, val, B, C0.copy(), 0.5, 2.0, threads=4)
+    assert np.array_equal(one, many)
+    part = ref_cpu.spmm_csr(rowptr, col, val, B, C0.copy(), 0.5, 2.0, r0=100, r1=300, threads=3)
+    assert np.array_equal(part[100:300], one[100:300]) and np.array_equal(part[:100], C0[:100])

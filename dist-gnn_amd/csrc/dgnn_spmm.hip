@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 // is (columns per block) x 256 B instead of whole B rows.
 // ---------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int SEG_MAX = 256;   // longest run a plan may hand to one group (dgnn_plan: piece length)
+constexpr int SEG_MAX = 256;   // LDS strip of a 16-lane group, in entries (8-lane groups: half)
 
 // C-side access helpers: VWC floats per access, guarded per element against F.
 template <int VWC>
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
     const int4* __restrict__ seg, int32_t nseg, uint32_t nsegblocks,
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-    float* __restrict__ P, int64_t ldp, int32_t F, float alpha) {
+    float* __restrict__ P, int64_t ldp, int32_t F, float alpha, uint32_t k) {
   constexpr int G = 64 / L;
   constexpr int SEGM = SEG_MAX * L / 16;        // strip length: 256 entries (L = 16), 128 (L = 8)
   static_assert(U % 2 == 0, "entries are read two per ds_read_b128");
@@ -281,8 +281,23 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   const uint32_t q = nb >> 3, r = nb & 7, xcd = b & 7;
   const uint32_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   const uint32_t chunk = w / nsegblocks;
-  const uint32_t sb = w - chunk * nsegblocks;
-
+  // Inside a chunk the segment blocks are listed longest first, and an XCD's share of the work index is
+  // a contiguous range that may cover a fraction of a chunk -- which must not be "the long ones".
+  // A chunk is therefore dealt into k classes (class j = blocks j, j + k, j + 2k, ...: same mix of long
+  // and short runs in each; k = 8 / gcd(chunks, 8) makes every share a union of whole classes), and
+  // the classes an XCD owns in one chunk are walked together, longest first.
+  const uint32_t p = w - chunk * nsegblocks;
+  uint32_t sb = p;
+  if (k > 1) {
+    const uint32_t qc = nsegblocks / k;                       // blocks per class (nsegblocks % k == 0)
+    const uint32_t share = nb >> 3;                           // nb % 8 == 0 here
+    const uint32_t v0 = xcd * share, c0 = chunk * nsegblocks;
+    const uint32_t lo = (v0 > c0 ? v0 - c0 : 0u);
+    const uint32_t hi = min(v0 + share - c0, nsegblocks);
+    const uint32_t j0 = lo / qc, ncl = hi / qc - j0;
+    const uint32_t t = p - lo;
+    sb = (t / ncl) * k + j0 + t % ncl;
+  }
   const int64_t sidx = ((int64_t)sb * 4 + wave) * G + g;
   const int fbase = (chunk * L + li) * 4;
   const bool live = sidx < nseg;
@@ -300,58 +315,64 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
   if (live && direct) c_load<VWC>(dst, fbase, F, a01, a23);   // pieces start from 0, direct runs from C
 
-  // Phase 1: the whole run's (col, val) stream -- cold data, read once, HBM/Infinity-Cache
-  // latency -- is fetched up front, all loads in flight together, and parked in LDS. Vector
-  // loads return in order, so a cold load issued between gather rounds would stall every
-  // younger (L2-hit) gather behind it; this way the run pays that latency once.
-  const int len = ke - kb;                      // <= SEG_MAX (plan piece length)
+  // A run is walked strip by strip (SEGM entries). Per strip --
+  // Phase 1: the strip's (col, val) stream -- cold data, read once, HBM/Infinity-Cache latency -- is
+  // fetched up front, all loads in flight together, and parked in LDS. Vector loads return in order, so
+  // a cold load issued between gather rounds would stall every younger (L2-hit) gather behind it; this
+  // way a strip pays that latency once. The strip is private to the group (one wave, in-order LDS), so
+  // no barrier separates the phases or consecutive strips.
 #pragma unroll 1
-  for (int t0 = 0; t0 * L < len; t0 += 4) {     // 64 entries (8 loads per lane) in flight per trip
-    uint32_t cx[4], vy[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {               // clamped, branch-free: tail lanes re-read the last entry
-      const int kk = min(kb + li + (t0 + t) * L, ke - 1);
-      cx[t] = (uint32_t)col[kk];
-      vy[t] = __float_as_uint(val[kk]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint32_t x = WIDE ? cx[t] : cx[t] * ldb_bytes;
-      ent[(li + (t0 + t) * L) & (SEGM - 1)] = make_uint2(x, __float_as_uint(alpha * __uint_as_float(vy[t])));
-    }
-  }
-  // Phase 2: gather rounds, U rows of B in flight per lane.
-  int j = 0;
+  for (int sb0 = kb; sb0 < ke; sb0 += SEGM) {
+    const int se = min(sb0 + SEGM, ke);
+    const int len = se - sb0;
 #pragma unroll 1
-  for (; j + U <= len; j += U) {
-    uint4 e[U / 2];
+    for (int t0 = 0; t0 * L < len; t0 += 4) {   // 64 entries (8 loads per lane) in flight per trip
+      uint32_t cx[4], vy[4];
 #pragma unroll
-    for (int h = 0; h < U / 2; ++h) e[h] = *reinterpret_cast<const uint4*>(&ent[j + 2 * h]);
-    float4 bb[U];
+      for (int t = 0; t < 4; ++t) {             // clamped, branch-free: tail lanes re-read the last entry
+        const int kk = min(sb0 + li + (t0 + t) * L, se - 1);
+        cx[t] = (uint32_t)col[kk];
+        vy[t] = __float_as_uint(val[kk]);
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t x = (u & 1) ? e[u / 2].z : e[u / 2].x;
-      if constexpr (WIDE) bb[u] = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)x * ldb_bytes + loff));
-      else bb[u] = *reinterpret_cast<const float4*>(Bbytes + (x + loff));
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t x = WIDE ? cx[t] : cx[t] * ldb_bytes;
+        ent[(li + (t0 + t) * L) & (SEGM - 1)] = make_uint2(x, __float_as_uint(alpha * __uint_as_float(vy[t])));
+      }
     }
+    // Phase 2: gather rounds, U rows of B in flight per lane.
+    int j = 0;
+#pragma unroll 1
+    for (; j + U <= len; j += U) {
+      uint4 e[U / 2];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float v = __uint_as_float((u & 1) ? e[u / 2].w : e[u / 2].y);
+      for (int h = 0; h < U / 2; ++h) e[h] = *reinterpret_cast<const uint4*>(&ent[j + 2 * h]);
+      float4 bb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t x = (u & 1) ? e[u / 2].z : e[u / 2].x;
+        if constexpr (WIDE) bb[u] = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)x * ldb_bytes + loff));
+        else bb[u] = *reinterpret_cast<const float4*>(Bbytes + (x + loff));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float v = __uint_as_float((u & 1) ? e[u / 2].w : e[u / 2].y);
+        const f32x2 vv = {v, v};
+        a01 = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01);
+        a23 = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23);
+      }
+    }
+#pragma unroll 1
+    for (; j < len; ++j) {
+      const uint2 e = ent[j];
+      float4 bb;
+      if constexpr (WIDE) bb = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)e.x * ldb_bytes + loff));
+      else bb = *reinterpret_cast<const float4*>(Bbytes + (e.x + loff));
+      const float v = __uint_as_float(e.y);
       const f32x2 vv = {v, v};
-      a01 = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01);
-      a23 = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23);
+      a01 = __builtin_elementwise_fma(vv, (f32x2){bb.x, bb.y}, a01);
+      a23 = __builtin_elementwise_fma(vv, (f32x2){bb.z, bb.w}, a23);
     }
-  }
-#pragma unroll 1
-  for (; j < len; ++j) {
-    const uint2 e = ent[j];
-    float4 bb;
-    if constexpr (WIDE) bb = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)e.x * ldb_bytes + loff));
-    else bb = *reinterpret_cast<const float4*>(Bbytes + (e.x + loff));
-    const float v = __uint_as_float(e.y);
-    const f32x2 vv = {v, v};
-    a01 = __builtin_elementwise_fma(vv, (f32x2){bb.x, bb.y}, a01);
-    a23 = __builtin_elementwise_fma(vv, (f32x2){bb.z, bb.w}, a23);
   }
 
   if (live) {
@@ -532,14 +553,18 @@ int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_
                  const float* B, int64_t ldb, float* C, int64_t ldc, float* P, int64_t ldp,
                  int32_t F, float alpha, hipStream_t s) {
   constexpr int G = 64 / L;
-  const int64_t nsegblocks = ((int64_t)nseg + 4 * G - 1) / (4 * G);   // 4 waves x G groups per workgroup
+  int64_t nsegblocks = ((int64_t)nseg + 4 * G - 1) / (4 * G);         // 4 waves x G groups per workgroup
   const int64_t nchunks = (ldb / 4 + L - 1) / L;
+  int64_t gcd8 = 8;
+  while (nchunks % gcd8) gcd8 >>= 1;
+  const uint32_t k = g_variant == 3 ? 1u : (uint32_t)(8 / gcd8);       // classes per chunk (see the kernel)
+  nsegblocks = (nsegblocks + k - 1) / k * k;                           // equal classes; tail blocks idle
   const int64_t nb = nsegblocks * nchunks;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "stage grid out of range%s (%lld)", "", nb);
   ProfScope prof(s, 0);
 #define DGNN_STAGE(VWC, WIDE)                                                                             \
   hipLaunchKernelGGL((spmm_stage_kernel<L, U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
-                     (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha)
+                     (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha, k)
   if (wide) { if (vwc == 4) DGNN_STAGE(4, true); else if (vwc == 2) DGNN_STAGE(2, true); else DGNN_STAGE(1, true); }
   else { if (vwc == 4) DGNN_STAGE(4, false); else if (vwc == 2) DGNN_STAGE(2, false); else DGNN_STAGE(1, false); }
 #undef DGNN_STAGE
@@ -686,8 +711,8 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
     DGNN_HIP(hipGetLastError());
   }
   if (plan->nstage <= 0 || !plan->stage_seg_off || plan->stage_seg_off[plan->nstage] == 0) return DGNN_OK;
-  if (plan->max_seg_len <= 0 || plan->max_seg_len > SEG_MAX)
-    return fail(DGNN_E_BADARG, "spmm_plan: plan->max_seg_len must be in 1..256%s (%lld)", "", plan->max_seg_len);
+  if (plan->max_seg_len <= 0)
+    return fail(DGNN_E_BADARG, "spmm_plan: plan->max_seg_len must be positive%s (%lld)", "", plan->max_seg_len);
   if (!plan->seg || !plan->stage_cut_off || !col || !val || !B)
     return fail(DGNN_E_BADARG, "spmm_plan: null pointer%s", "");
   if (ldb < F || ldb % 4 != 0 || !aligned(B, 16))
@@ -707,7 +732,7 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
       // 8-lane groups (128-B chunks) when B is at most 256 floats wide: enough chunks for the 8 XCDs to
       // work on different ones (measured +22 % at F = 256, +25 % at F = 41); 16-lane groups above.
       const bool narrow = (g_variant == 8) || (g_variant != 16 && ldb <= 256);
-      if (narrow && plan->max_seg_len <= SEG_MAX / 2)
+      if (narrow)
         rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
       else
         rc = launch_stage<16, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);

@@ -201,8 +201,7 @@ _lib.dgnn_spmm_plan_f32.argtypes = [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, 
                                     _i32, _f32, _f32, _p]
 _lib.dgnn_spmm_plan_f32.restype = ctypes.c_int
 
-PIECE_LEN = 128              # runs longer than this are cut (bounds the per-stage critical path; <= 128
-                             # lets the kernel use 8-lane groups for narrow feature blocks)
+PIECE_LEN = 4096             # longest run one lane group walks (strip by strip); longer runs are cut and merged
 
 
 def padded_width(F):
@@ -250,17 +249,34 @@ def gather_rows(src, idx, dst=None):
 
 
 def default_stage_count(n, m, nnz, F):
-    """Column-block stages for a block (measured on MI355X, Reddit-shape sweeps in DESIGN.md):
-    one stage while the padded B fits the Infinity Cache comfortably; otherwise enough stages that one
-    feature chunk of one column block is ~4 MiB (8-lane groups, ld <= 256) or ~16 MiB (16-lane groups),
-    never so many that a (row, column block) run averages under ~16 nonzeros."""
+    """Column-block stages for a block (measured on MI355X, sweeps on Reddit- and products-shaped blocks of
+    the 1/2/4/8-rank partitions): enough stages that one feature chunk of one column block is
+    ~4 MiB of B (8-lane groups, 64 < ld <= 256) or ~16 MiB (16-lane groups; or ld <= 64, where the kernel
+    already runs at the L2 gather ceiling from the Infinity Cache), never so many that a (row, column block)
+    run averages under ~16 nonzeros, at most 16."""
     ld = padded_width(F)
-    if n == 0 or m * ld * 4 <= (128 << 20):
+    if n == 0 or nnz == 0:
         return 1
-    chunk_bytes, budget = (128, 4 << 20) if ld <= 256 else (256, 16 << 20)
-    by_cache = -(-m * chunk_bytes // budget)
+    if ld > 256:
+        chunk_bytes, budget = 256, 16 << 20
+    elif ld > 64:
+        chunk_bytes, budget = 128, 4 << 20
+    else:
+        chunk_bytes, budget = 128, 16 << 20
+    by_cache = int(m * chunk_bytes / budget + 0.5)
     by_density = max(1, int(nnz / max(n, 1) / 16))
     return int(max(1, min(by_cache, by_density, 16)))
+
+
+def default_piece_len(nnz, nstage):
+    """Longest run handed to one lane group. Longer pieces mean fewer partial rows to merge and more rows
+    with the oracle's exact chain; shorter ones balance small blocks. Measured optimum ~ nnz per stage /
+    7000 (256-512 for a 1.8 M-nonzero block, 4096 from ~30 M up), as a power of two in [128, PIECE_LEN]."""
+    want = max(1.0, nnz / max(nstage, 1) / 7000.0)
+    p = 128
+    while p * 1.41 < want and p < PIECE_LEN:
+        p *= 2
+    return p
 
 
 class SegPlan:
@@ -270,12 +286,14 @@ class SegPlan:
     block's device; the result is deterministic for a given block, stage count and piece length.
     """
 
-    def __init__(self, A, nstage=1, piece_len=PIECE_LEN):
+    def __init__(self, A, nstage=1, piece_len=None):
         dev = A.device
         rp = A.rowptr.long()
         n, nnz = A.n, A.nnz
-        if not 1 <= piece_len <= 256:
-            raise ValueError('piece_len must be in 1..256 (one LDS strip per lane group)')
+        if piece_len is None:
+            piece_len = int(os.environ.get('DGNN_PIECE_LEN', 0)) or default_piece_len(A.nnz, nstage)
+        if not 1 <= piece_len < 2 ** 31:
+            raise ValueError('piece_len must be positive')
         nstage = max(1, int(nstage))
         cbw = max(1, -(-A.m // nstage))
         self.nstage, self.piece_len = nstage, piece_len

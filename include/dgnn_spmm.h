@@ -108,7 +108,7 @@ int dgnn_gather_rows_f32(const float* src, int64_t lds, int32_t nsrc, const int3
  *
  * The column range [0, m) is cut into `nstage` equal blocks. A segment is the run of one
  * row's nonzeros that falls into one column block: positions [k0, k1) of col/val. Runs
- * longer than the plan's piece length (at most 256) are cut into pieces; piece p of a cut run has
+ * longer than the plan's piece length are cut into pieces; piece p of a cut run has
  * out = pbase + p (a row of the `partial` buffer), an uncut run has out = -1.
  *   seg            device, int32[4 * nseg]: {row, k0, k1, out} per entry, grouped by stage,
  *                  longest first inside a stage
@@ -125,7 +125,7 @@ typedef struct dgnn_plan {
   const int32_t* cut;
   const int64_t* stage_cut_off;
   int64_t npartial;
-  int32_t max_seg_len;      /* longest k1 - k0 in `seg`; must be <= 256 (one LDS strip per group) */
+  int32_t max_seg_len;      /* longest k1 - k0 in `seg` (> 0); bounds the critical path of a stage */
 } dgnn_plan;
 
 /*

@@ -171,6 +171,12 @@ PLAN_CASES = [
     (100, 100, 2000, 0, 16, 2, 16, -1.0, 0.25),
     (64, 4096, 3000, 0, 1433, 4, 256, 1.0, 1.0),
     (4000, 100, 50000, 0, 64, 1, 8, 1.0, 1.0),
+    # runs longer than one LDS strip (256 entries for 16-lane groups, 128 for 8-lane groups): walked strip by strip
+    (1000, 900, 60000, 2, 602, 1, 4096, 1.0, 1.0),
+    (3000, 3000, 90000, 3, 256, 1, 1000000, 1.0, 1.0),      # nothing cut: every row must carry the oracle's bits
+    (2000, 6000, 120000, 3, 41, 2, 1024, 1.0, 1.0),
+    (1500, 5000, 100000, 2, 100, 1, 300, 0.5, 1.0),         # piece length that is no multiple of the strip
+    (900, 7000, 80000, 2, 1433, 3, 700, 1.0, 0.0),
 ]
 
 

@@ -90,7 +90,7 @@ def main():
         specs = [x for x in args.plans.split(';') if x]
         for spec in specs:
             if spec == 'auto':
-                ns, pl_len = spmm_cpp.default_stage_count(A.n, A.m, A.nnz, F), spmm_cpp.PIECE_LEN
+                ns = spmm_cpp.default_stage_count(A.n, A.m, A.nnz, F); pl_len = spmm_cpp.default_piece_len(A.nnz, ns)
             else:
                 ns, pl_len = (int(x) for x in spec.split(':')[:2])
             nhot = 0

@@ -263,7 +263,7 @@ def default_stage_count(n, m, nnz, F):
         chunk_bytes, budget = 128, 4 << 20
     else:
         chunk_bytes, budget = 128, 16 << 20
-    by_cache = int(m * chunk_bytes / budget + 0.5)
+    by_cache = -(-m * chunk_bytes // budget)
     by_density = max(1, int(nnz / max(n, 1) / 16))
     return int(max(1, min(by_cache, by_density, 16)))
 

@@ -729,11 +729,16 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
       const int4* seg = reinterpret_cast<const int4*>(plan->seg) + s0;
       int rc;
       const int32_t ns = (int32_t)(s1 - s0);
-      // 8-lane groups (128-B chunks) when B is at most 256 floats wide: enough chunks for the 8 XCDs to
-      // work on different ones (measured +22 % at F = 256, +25 % at F = 41); 16-lane groups above.
-      const bool narrow = (g_variant == 8) || (g_variant != 16 && ldb <= 256);
+      // 16-lane groups (256-B slices of a B row per gather), 32-lane groups for wide blocks. 8-lane groups (128-B slices) looked
+      // better for narrow blocks only while XCD shares were unbalanced (more chunks hid it); with balanced
+      // shares they are 5-25 % slower at every width measured. Kept behind the variant knob for A/B runs.
+      const bool narrow = (g_variant == 8);
       if (narrow)
         rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      else if (g_variant == 32 || (g_variant == 0 && ldb >= 256))   // 512-B slices: 3-9 % faster from 256 floats up
+        rc = launch_stage<32, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      else if (g_variant == 64)
+        rc = launch_stage<64, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
       else
         rc = launch_stage<16, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
       if (rc != DGNN_OK) return rc;

@@ -42,7 +42,7 @@ def test_binding_rejects_cpu_tensors():
         spmm_cpp.spmm_cusparse(i, i, torch.ones(1), 1, 1, torch.ones(1, 1), torch.ones(1, 1), 1, 1)
     assert spmm_cpp.padded_width(602) == 608 and spmm_cpp.padded_width(41) == 64 and spmm_cpp.padded_width(256) == 256
     assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 602) == 4
-    assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 256) == 8
+    assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 256) == 4
     assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 41) == 2
     assert spmm_cpp.default_stage_count(29121, 29121, 1819992, 602) == 1          # a block of the 8-rank partition
     assert spmm_cpp.default_stage_count(2449029, 2449029, 126167309, 100) == 3    # products: capped by run length

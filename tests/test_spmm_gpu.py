@@ -287,3 +287,53 @@ def test_gather_rows_is_an_exact_copy(F, ldd):
         spmm_cpp.gather_rows(src, idx.long(), dst)
     with pytest.raises(RuntimeError, match='overlap'):
         spmm_cpp.gather_rows(dst, idx, dst)
+
+
+@pytest.mark.parametrize('variant', [2, 3, 8, 16, 32, 64])
+def test_kernel_variants_agree_bit_for_bit(variant):
+    """The A/B knobs (64-bit offsets, contiguous XCD shares, 8/16/32/64-lane groups) only change how the work
+    is laid out: same accumulation chain, so the same bits as the default dispatch."""
+    import spmm_cpp
+    rng = np.random.default_rng(77)
+    n, m, F = 1500, 2500, 300
+    row, col, val = _rand_csr(rng, n, m, 70000, hub_rows=3)
+    blk = _gpu_block(row, col, val, n, m)
+    dev = torch.device('cuda:0')
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(rng.standard_normal((m, F), dtype=np.float32)).to(dev))
+    C0 = torch.from_numpy(rng.standard_normal((n, F), dtype=np.float32)).to(dev)
+    plan = spmm_cpp.SegPlan(blk, 3, 600)
+    base = C0.clone()
+    spmm_cpp.spmm_plan(blk, Bp, base, 1.0, 1.0, plan)
+    try:
+        spmm_cpp.set_variant(variant)
+        got = C0.clone()
+        spmm_cpp.spmm_plan(blk, Bp, got, 1.0, 1.0, plan)
+    finally:
+        spmm_cpp.set_variant(0)
+    assert torch.equal(got, base)
+
+
+def test_feature_blocks_beyond_4_gib_use_wide_offsets():
+    """B larger than 4 GiB (papers-shaped blocks): the stage kernel switches to 64-bit row offsets on its own.
+    Checked against the general row kernel (64-bit addressing throughout) on rows the plan does not cut."""
+    import spmm_cpp
+    dev = torch.device('cuda:0')
+    m, F, n = 1_100_000, 1000, 600                      # padded B: 1.1 M x 1024 floats = 4.5 GB
+    g = torch.Generator(device=dev).manual_seed(9)
+    B = torch.rand(m, spmm_cpp.padded_width(F), device=dev, generator=g)
+    rng = np.random.default_rng(9)
+    row = np.repeat(np.arange(n, dtype=np.int32), 40)
+    col = np.sort(rng.integers(0, m, (n, 40)), axis=1)
+    col[:, -1] = m - 1 - np.arange(n) % 7               # touch the last rows of B: offsets past 2^32 bytes
+    col = np.sort(col, axis=1)
+    keep = np.concatenate([np.ones((n, 1), bool), col[:, 1:] != col[:, :-1]], axis=1).ravel()
+    row, col = row[keep], col.ravel()[keep].astype(np.int32)
+    val = rng.random(row.size, dtype=np.float32)
+    blk = _gpu_block(row, col, val, n, m)
+    want = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_csr(blk, B[:, :F], want, 1.0, 0.0)
+    got = torch.full((n, F), float('nan'), device=dev)
+    spmm_cpp.spmm_plan(blk, B, got, 1.0, 0.0, spmm_cpp.SegPlan(blk, 2))
+    assert torch.equal(got, want)
+    del B
+    torch.cuda.empty_cache()

@@ -82,8 +82,11 @@ class GraphCache:
 
 class BlockList(list):
     """``adj_parts``: the list of column blocks A[rank, j]; ``transposed`` optionally holds the
-    blocks (A^T)[rank, j] for a backward pass that is exact on asymmetric graphs."""
+    blocks (A^T)[rank, j] for a backward pass that is exact on asymmetric graphs; ``slab`` is the
+    whole row block A[rank, :] the list was cut from (global column ids), which lets the all-gather
+    form of the pipeline aggregate in one SpMM."""
     transposed = None
+    slab = None
 
 
 def csr_arrays(block):
@@ -197,11 +200,13 @@ class Parted_COO_Graph(BasicGraph):
         self.local_labels = self.labels[lo:hi]
         self.local_train_mask = self.train_mask[lo:hi].bool()
         self.adj_parts = BlockList(graph_utils.sparse_2d_split(self.adj, self.local_num_nodes, split_dim=1))
+        self.adj_parts.slab = self.adj
         if transposed_backward:
             if 'adj_t' not in attr_dict:
                 raise Exception('transposed_backward needs part files written with partition(..., with_transpose=True)')
-            self.adj_parts.transposed = graph_utils.sparse_2d_split(attr_dict['adj_t'].to(device), self.local_num_nodes,
-                                                                    split_dim=1)
+            adj_t = attr_dict['adj_t'].to(device)
+            self.adj_parts.transposed = BlockList(graph_utils.sparse_2d_split(adj_t, self.local_num_nodes, split_dim=1))
+            self.adj_parts.transposed.slab = adj_t
         self.csr_from_file = self._attach_csr(attr_dict, 'csr', self.adj_parts)
         if self.adj_parts.transposed is not None:
             self._attach_csr(attr_dict, 'csrt', self.adj_parts.transposed)

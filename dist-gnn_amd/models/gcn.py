@@ -137,7 +137,9 @@ class StagePipeline:
                       multiplied, stages j+1 .. j+inflight-1 are already in flight.
     mode 'allgather'  one all-gather of every rank's block (the P broadcasts of a layer pass
                       are together an all-gather; one collective keeps every xGMI link busy),
-                      then the P SpMMs.
+                      then ONE SpMM of the rank's whole row slab against the gathered matrix when the
+                      block list carries the slab (Parted_COO_Graph sets it; DGNN_FUSED_SLAB=0 or a
+                      plain list fall back to the P per-block SpMMs).
     mode 'needed'     point-to-point: the owner of stage j sends every peer only the rows of H_j
                       that peer's block references (NeededRows), pipelined like 'bcast'.
     mode 'auto'       (default) the first time a (tag, shape) is aggregated, the forms are run
@@ -170,6 +172,7 @@ class StagePipeline:
         self.transfers = 0             # blocks actually moved (tests / logs)
         self.rows_moved = 0            # feature rows received by this rank ...
         self.rows_full = 0             # ... and what whole blocks would have been
+        self.fused_slab = os.environ.get('DGNN_FUSED_SLAB', '1') == '1'
         self.choice = {}               # (tag, rows, width, group size) -> (form, {form: seconds}) picked by 'auto'
 
     def _buffers(self, shape, like, count, tag=''):
@@ -220,6 +223,16 @@ class StagePipeline:
         with timer.timing_cuda('broadcast'):
             dist.all_gather_into_tensor(gathered, own, group=group)
         self.transfers += P                                  # same count as P rooted broadcasts
+        slab = getattr(adj_parts, 'slab', None) if self.fused_slab else None
+        if slab is not None and slab.size(1) == P * s and [src for src, _ in stages] == list(range(P)):
+            # the gathered matrix is H in global row order and the rank's row slab A[rank, :] has global
+            # column ids: ONE SpMM instead of P -- z is written once instead of read and written per
+            # stage (what dominates on sparse graphs), same ascending-column chain for every row
+            if keep is not None:
+                keep['gathered'] = gathered
+            with timer.timing_cuda('spmm'):
+                spmm(slab, gathered[:, :F] if ld != F else gathered, z)
+            return z
         members = sorted(src for src, _ in stages)
         for src, blk in stages:
             pos = members.index(src)
@@ -425,6 +438,10 @@ class StagePipeline:
         if cacheable:
             hit = self._input_cache.get(tag)
             if hit is not None and hit[0] == self._tensor_key(orig):
+                if 'gathered' in hit[1]:
+                    with timer.timing_cuda('spmm'):
+                        spmm(adj_parts.slab, hit[1]['gathered'][:, :feat.size(1)], z)
+                    return z
                 for src, blk in stages:
                     with timer.timing_cuda('spmm'):
                         spmm(adj_parts[blk], feat if src == rank else hit[1][src], z)

@@ -117,9 +117,14 @@ def test_transfer_forms_over_rccl_world1(env, F):
     z2 = pipe._run_allgather([A], H, stages, env.world_group, torch.zeros(n, F, device=dev), None)
     keep = {}
     z3 = pipe._run_bcast([A], H, stages, env.world_group, torch.zeros(n, F, device=dev), keep, None)
+    from coo_graph.parted_coo_graph import BlockList
+    parts = BlockList([A])
+    parts.slab = A                                      # one rank: the row slab is the block itself
+    kept = {}
+    z4 = pipe._run_allgather(parts, H, stages, env.world_group, torch.zeros(n, F, device=dev), kept)
     torch.cuda.synchronize()
-    assert torch.equal(z1, want) and torch.equal(z2, want) and torch.equal(z3, want)
-    assert pipe.transfers == 3
+    assert torch.equal(z1, want) and torch.equal(z2, want) and torch.equal(z3, want) and torch.equal(z4, want)
+    assert 'gathered' in kept and pipe.transfers == 4
 
 
 @pytest.mark.parametrize('F', [602, 100, 41])

@@ -139,6 +139,11 @@ def scenario_input_cache(env, rank, world, gold_dir):
         gcn._pipeline = gcn.StagePipeline(cache_input=on)
         losses = dist_train.train(g, env, total_epoch=3, eval_every=0)
         res[on] = dict(losses=losses, transfers=gcn.pipeline().transfers)
+    # the all-gather form with the fused slab SpMM keeps the gathered matrix instead of per-source blocks
+    gcn._pipeline = gcn.StagePipeline(mode='allgather', cache_input=True)
+    losses = dist_train.train(g, env, total_epoch=3, eval_every=0)
+    kept = gcn.pipeline()._input_cache['ForwardL1'][1]
+    res['allgather'] = dict(losses=losses, transfers=gcn.pipeline().transfers, fused='gathered' in kept)
     g.features.mul_(1.0)        # in-place write bumps the version counter: the cache must not be reused
     gcn._pipeline = gcn.StagePipeline(cache_input=True)
     gcn.broadcast(g.adj_parts, g.features, 'ForwardL1'); gcn.broadcast(g.adj_parts, g.features, 'ForwardL1')
@@ -306,5 +311,7 @@ def test_input_cache_is_lossless(tmp_path):
         assert res[True]['losses'] == res[False]['losses']               # bit-identical training
         assert res[False]['transfers'] == 2 * 3 * 6                      # 3 epochs x 6 passes x (1 send + 1 recv counted per rank)
         assert res[True]['transfers'] == 2 * (3 * 6 - 2)                 # layer-1 forward sent in epoch 0 only
+        assert res['allgather']['fused'] and res['allgather']['losses'] == res[False]['losses']
+        assert res['allgather']['transfers'] == 2 * (3 * 6 - 2)
         a, b = res['after_write']
         assert a == 2 and b == 4                                         # a write to the features invalidates the cache

@@ -98,6 +98,30 @@ class NeededRows:
         self.local_fraction = float(self.K[rank].sum()) / max(1, (P - 1) * self.block_rows)
 
     @staticmethod
+    def fraction_needed(adj_parts, group):
+        """Share of the feature rows that have to travel at all, over the whole job (same value on every
+        rank: one all-reduce). Cheap test before building anything: one bincount per block."""
+        got = getattr(adj_parts, '_dgnn_needed_fraction', None)
+        if got is not None:
+            return got
+        env = DistEnv.env
+        need = 0
+        for src, A in enumerate(adj_parts):
+            if src != env.rank and A._nnz():
+                A = A if A.is_coalesced() else A.coalesce()
+                need += int(torch.count_nonzero(torch.bincount(A.indices()[1], minlength=A.size(1))))
+        dev = adj_parts[0].device if dist.get_backend(group) == 'nccl' else 'cpu'
+        t = torch.tensor([float(need)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, group=group)
+        P = env.world_size
+        got = float(t.item()) / max(1, P * (P - 1) * adj_parts[0].size(1))
+        try:
+            adj_parts._dgnn_needed_fraction = got
+        except AttributeError:
+            pass
+        return got
+
+    @staticmethod
     def of(adj_parts, group):
         nr = getattr(adj_parts, '_dgnn_needed', None)
         if nr is None:
@@ -366,7 +390,7 @@ class StagePipeline:
         sent = self.transfers
 
         forms = ['bcast', 'allgather']
-        if self._needed_ok(adj_parts, stages, group) and NeededRows.of(adj_parts, group).fraction < 0.75:
+        if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.75:
             forms.append('needed')
         moved = (self.rows_moved, self.rows_full)
 

@@ -489,6 +489,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
+// One uncut segment per row, in row order: the work list of the stage kernel for a block nobody planned.
+__global__ __launch_bounds__(256) void rows_plan_kernel(const int32_t* __restrict__ rowptr, int32_t n,
+                                                        int4* __restrict__ seg) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    seg[i] = make_int4((int)i, rowptr[i], rowptr[i + 1], -1);
+}
+
 unsigned capped_blocks(int64_t work, unsigned cap) {
   const int64_t b = (work + 255) / 256;
   return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -692,6 +700,24 @@ int dgnn_spmm_coo_f32(const int32_t* row, const int32_t* col, const float* val,
   int rc = dgnn_coo2csr_i32(row, nnz, n, rowptr_ws, stream);
   if (rc != DGNN_OK) return rc;
   return dgnn_spmm_csr_f32(rowptr_ws, col, val, n, m, nnz, B, ldb, C, ldc, F, alpha, beta, stream);
+}
+
+int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const float* val,
+                              int32_t n, int32_t m, int64_t nnz, int32_t* rowptr_ws, int32_t* seg_ws,
+                              const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                              float alpha, float beta, void* stream) {
+  if (n == 0 || F == 0) return DGNN_OK;
+  if (!seg_ws || !aligned(seg_ws, 16)) return fail(DGNN_E_BADARG, "spmm_coo_aligned: seg_ws must be a 16-byte aligned int32[4n]%s", "");
+  int rc = dgnn_coo2csr_i32(row, nnz, n, rowptr_ws, stream);
+  if (rc != DGNN_OK) return rc;
+  hipLaunchKernelGGL(rows_plan_kernel, dim3(capped_blocks(n, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     rowptr_ws, n, reinterpret_cast<int4*>(seg_ws));
+  DGNN_HIP(hipGetLastError());
+  const int64_t seg_off[2] = {0, n}, cut_off[2] = {0, 0};
+  dgnn_plan plan;
+  plan.nstage = 1; plan.seg = seg_ws; plan.stage_seg_off = seg_off; plan.cut = nullptr;
+  plan.stage_cut_off = cut_off; plan.npartial = 0; plan.max_seg_len = 0x7fffffff;
+  return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, nullptr, 0, F, alpha, beta, stream);
 }
 
 int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* val,

@@ -82,6 +82,9 @@ def _dense(t, name):
     return t.data_ptr(), ld
 
 
+_FAST_COO_MIN_NNZ = 1 << 16
+
+
 def spmm_cusparse(A_row_idx, A_col_idx, A_values, A_row, A_col, B, C, alpha, beta):
     """C <- alpha * A @ B + beta * C in place; A is row-sorted COO (int32 indices, fp32 values).
 
@@ -105,9 +108,17 @@ def spmm_cusparse(A_row_idx, A_col_idx, A_values, A_row, A_col, B, C, alpha, bet
         raise RuntimeError('spmm_cpp: operands are on different devices')
     with torch.cuda.device(C.device):
         ws = torch.empty(n + 1, dtype=torch.int32, device=C.device)
-        rc = _lib.dgnn_spmm_coo_f32(A_row_idx.data_ptr(), A_col_idx.data_ptr(), A_values.data_ptr(),
-                                    n, m, nnz, ws.data_ptr(), bptr, ldb, cptr, ldc, F,
-                                    float(alpha), float(beta), _stream(C))
+        if nnz >= _FAST_COO_MIN_NNZ and F >= 8:
+            # big enough to pay for a padded copy of B: the staged kernel on a one-run-per-row work list
+            Bp = B if (ldb % 4 == 0 and B.data_ptr() % 16 == 0) else pad_rows(B, _pad_buffer(m, padded_width(F), B.device))
+            seg = torch.empty(4 * n, dtype=torch.int32, device=C.device)
+            rc = _lib.dgnn_spmm_coo_aligned_f32(A_row_idx.data_ptr(), A_col_idx.data_ptr(), A_values.data_ptr(),
+                                                n, m, nnz, ws.data_ptr(), seg.data_ptr(), Bp.data_ptr(), Bp.stride(0),
+                                                cptr, ldc, F, float(alpha), float(beta), _stream(C))
+        else:
+            rc = _lib.dgnn_spmm_coo_f32(A_row_idx.data_ptr(), A_col_idx.data_ptr(), A_values.data_ptr(),
+                                        n, m, nnz, ws.data_ptr(), bptr, ldb, cptr, ldc, F,
+                                        float(alpha), float(beta), _stream(C))
     _check(rc, 'spmm_cusparse')
 
 
@@ -223,6 +234,8 @@ def pad_rows(src, dst=None):
     return dst
 
 
+_lib.dgnn_spmm_coo_aligned_f32.argtypes = [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p]
+_lib.dgnn_spmm_coo_aligned_f32.restype = ctypes.c_int
 _lib.dgnn_gather_rows_f32.argtypes = [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]
 _lib.dgnn_gather_rows_f32.restype = ctypes.c_int
 

@@ -147,6 +147,19 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
                        int32_t F, float alpha, float beta, void* stream);
 
 /*
+ * spmm_cusparse's operand list (row-sorted COO, spmm.cpp:16-17) on the fast kernel, for callers that hand
+ * over a fresh COO every call as the reference's models do (gcn.py:11) and so cannot keep a plan: the
+ * work list is one uncut run per row, in row order (no column stages, no longest-first order, hub rows
+ * are the critical path), built on the stream into `seg_ws`. Same bits as dgnn_spmm_coo_f32.
+ *   B           ldb % 4 == 0, 16-byte aligned base (dgnn_pad_rows_f32)
+ *   rowptr_ws   int32[n + 1] workspace;  seg_ws  int32[4 * n] workspace, 16-byte aligned
+ */
+int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const float* val,
+                              int32_t n, int32_t m, int64_t nnz, int32_t* rowptr_ws, int32_t* seg_ws,
+                              const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                              float alpha, float beta, void* stream);
+
+/*
  * Measurement hooks (no counterpart in the reference). Between dgnn_prof_begin() and
  * dgnn_prof_end() every kernel launch of dgnn_spmm_plan_f32 / dgnn_pad_rows_f32 is bracketed by
  * HIP events on its own stream. dgnn_prof_end() waits for them and returns the summed

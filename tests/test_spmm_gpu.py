@@ -337,3 +337,25 @@ def test_feature_blocks_beyond_4_gib_use_wide_offsets():
     assert torch.equal(got, want)
     del B
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('n,m,nnz,F,alpha,beta', [(2500, 2500, 150000, 602, 1.0, 1.0), (4000, 1500, 90000, 256, 1.0, 0.0),
+                                                  (1200, 5000, 120000, 41, 0.5, 2.0), (3000, 3000, 80000, 100, -1.0, 1.0)])
+def test_reference_signature_takes_the_fast_kernel_without_a_plan(n, m, nnz, F, alpha, beta):
+    """spmm_cusparse(row, col, val, ...) with enough nonzeros runs the staged kernel on a one-run-per-row work
+    list (dgnn_spmm_coo_aligned_f32; B is padded on the way in). No row is cut: the oracle's bits."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    assert nnz >= spmm_cpp._FAST_COO_MIN_NNZ
+    rng = np.random.default_rng(n + F)
+    row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=2)
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if beta == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), alpha, beta)
+    dev = torch.device('cuda:0')
+    Cg = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_cusparse(torch.from_numpy(row).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
+                           n, m, torch.from_numpy(B).to(dev), Cg, alpha, beta)
+    assert np.array_equal(Cg.cpu().numpy(), want)

@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--beta', type=float, default=1.0)
     ap.add_argument('--torch-ref', action='store_true')
     ap.add_argument('--plan-variants', default='0')
+    ap.add_argument('--drop-in', action='store_true', help='also time the reference-signature call spmm_cusparse(row, col, val, ...)')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -83,6 +84,23 @@ def main():
             print(f'F={F:4d} variant {v}: {med:8.3f} ms (best {best:.3f})  {A.nnz/med/1e6:7.2f} GEdges/s  '
                   f'alg {alg_bytes/med/1e6:7.1f} GB/s = {alg_bytes/med/1e6/8000:.3f} of 8 TB/s  '
                   f'gather {4*F*A.nnz/med/1e9:6.2f} TB/s{err}', flush=True)
+        if args.drop_in:
+            ci = adj.indices()
+            r32, c32, vv = ci[0].int(), ci[1].int(), adj.values()
+            C.zero_()
+            spmm_cpp.spmm_csr(A, B, C, 1.0, 0.0)
+            Cd = torch.full_like(C, float('nan'))
+            spmm_cpp.spmm_cusparse(r32, c32, vv, A.n, A.m, B, Cd, 1.0, 0.0)
+            same = torch.equal(C, Cd)
+            if not same:
+                d = (C - Cd).abs()
+                bad = torch.nonzero(d.amax(1) > 0).flatten()
+                print(f'# drop-in differs from the row kernel: max {d.max().item():.3e} in {bad.numel()} rows, first {bad[:8].tolist()}, '
+                      f'their lengths {(A.rowptr[bad[:8] + 1] - A.rowptr[bad[:8]]).tolist()}, nan {torch.isnan(Cd).sum().item()}', flush=True)
+            med, best = time_call(lambda: spmm_cpp.spmm_cusparse(r32, c32, vv, A.n, A.m, B, Cd, 1.0, args.beta), args.iters, args.warmup)
+            print(f'F={F:4d} spmm_cusparse(COO, no plan) {"=" if same else "~"}: {med:8.3f} ms (best {best:.3f})  '
+                  f'{A.nnz/med/1e6:7.2f} GEdges/s', flush=True)
+            del r32, c32
         C0 = torch.zeros(A.n, F, device=dev)
         spmm_cpp.set_variant(0)
         spmm_cpp.spmm_csr(A, B, C0, 1.0, 0.0)

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   const int kb = s.y, ke = s.z;
   const bool direct = s.w < 0;
   // lanes past the padded width gather a valid float4 (the row's last one) and never store it
+  const bool gathers = fbase < (int)ldb;
   const int fgather = min(fbase, (int)ldb - 4);
   const uint32_t loff = (uint32_t)fgather * 4u;
   const uint32_t ldb_bytes = (uint32_t)ldb * 4u;
@@ -340,7 +341,9 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
         ent[(li + (t0 + t) * L) & (SEGM - 1)] = make_uint2(x, __float_as_uint(alpha * __uint_as_float(vy[t])));
       }
     }
-    // Phase 2: gather rounds, U rows of B in flight per lane.
+    // Phase 2: gather rounds, U rows of B in flight per lane. Lanes past the padded width (last chunk
+    // of a width that is no multiple of the chunk) sit the rounds out: fewer lanes for the address unit.
+    if (!gathers) continue;
     int j = 0;
 #pragma unroll 1
     for (; j + U <= len; j += U) {

@@ -167,10 +167,12 @@ class StagePipeline:
     mode 'needed'     point-to-point: the owner of stage j sends every peer only the rows of H_j
                       that peer's block references (NeededRows), pipelined like 'bcast'.
     mode 'auto'       (default) the first time a (tag, shape) is aggregated, the forms are run
-                      and timed on the spot ('needed' joins when under 3/4 of the rows are needed), the slower rank's time decides (all-reduce MAX, so
-                      every rank picks the same form), and the choice sticks. Costs three extra
-                      aggregations in the first epoch; results do not depend on the choice.
-    All accumulate src = 0..P-1 in order, so z is bit-identical in every mode.
+                      and timed on the spot ('needed' joins when under 3/4 of the rows are
+                      needed), the slowest rank's time decides (all-reduce MAX, so every rank
+                      picks the same form), and the choice sticks. Costs a few extra aggregations
+                      in the first epoch; results do not depend on the choice.
+    All accumulate in ascending source (= column) order, so every row the work plans leave uncut
+    gets the same bits in every mode.
 
     Wire format: when padding a feature row to the kernel's 128-byte row pitch adds <= 1/16 to the
     bytes (602 -> 608 floats), the owner pads its block once and the padded block travels, so the
@@ -235,7 +237,7 @@ class StagePipeline:
             return 'auto'
         return 'auto(' + ', '.join(f'{k[0]}[{k[1]}x{k[2]}]={v[0]}' for k, v in sorted(self.choice.items())) + ')'
 
-    # ---- the two forms -------------------------------------------------------------------
+    # ---- the forms -------------------------------------------------------------------
     def _run_allgather(self, adj_parts, feat, stages, group, z, keep):
         env = DistEnv.env
         rank, timer = env.rank, env.timer

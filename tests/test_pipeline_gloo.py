@@ -129,3 +129,66 @@ def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
         got, want = np.array(out[0]['losses']), np.array(out[0]['gold_losses'])
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=6e-5)      # reference logs 4 decimals
         assert out[0]['acc_logged'] >= 2                                    # epochs 0 and 4 are evaluated
+
+
+def _cora_worker(rank, world, port, log_dir, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.set_num_threads(1)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DGNN_PIPELINE='auto', DGNN_LOG_DIR=log_dir)
+        import coo_graph
+        import dist_train
+        import dist_utils
+        from coo_graph import synthetic
+        from models import gcn
+        gcn.set_spmm_backend(_oracle_spmm, gather=_cpu_gather)
+        env = dist_utils.DistEnv(rank, world, 'gloo', echo=False)
+        raw = synthetic.make_dataset('cora', seed=0)
+        full = coo_graph.COO_Graph('cora', attr_dict=raw)
+        g = coo_graph.Parted_COO_Graph('cora', rank, world, attr_dict=full.partition(world, save=False)[rank])
+        z = gcn.broadcast(g.adj_parts, g.features, 'ForwardL1')
+        losses = dist_train.train(g, env, total_epoch=4, hidden_dim=256, num_layers=2, eval_every=0)
+        q.put((rank, dict(z=z.numpy(), losses=losses, n=full.num_nodes, shape=tuple(g.features.shape),
+                          ntrain=int(g.local_train_mask.sum()), rows=g.local_num_nodes)))
+        env.barrier_all()
+        torch.distributed.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+        raise e
+
+
+def _run_cora(world, tmp):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cora_worker, args=(r, world, port, tmp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r, res in out.items():
+        assert 'error' not in res, res.get('error')
+    return out
+
+
+def test_cora_shape_two_ranks_equal_one_rank(tmp_path):
+    """BASELINE config 0: Cora-shaped 2-layer GCN (2,708 nodes, 1,433 features, 7 classes), 1D partition over
+    two gloo ranks. The aggregation is the one-rank result bit for bit (row chains do not depend on P) and
+    the first epoch's loss over all training nodes is the one-rank loss. (Later epochs differ by design: like
+    the reference, every rank takes the MEAN loss of its own training nodes, dist_train.py:41-43, so the
+    summed gradient weights the ranks differently from a one-rank run.)"""
+    one = _run_cora(1, str(tmp_path / 'p1'))[0]
+    two = _run_cora(2, str(tmp_path / 'p2'))
+    assert one['shape'] == (2708, 1433) and two[0]['rows'] == 1354
+    n = one['n']
+    z2 = np.concatenate([two[0]['z'], two[1]['z']])[:n]
+    assert np.array_equal(z2, one['z'][:n])
+    w = np.array([two[0]['ntrain'], two[1]['ntrain']], dtype=np.float64)
+    first = (w * np.array([two[0]['losses'][0], two[1]['losses'][0]])).sum() / w.sum()
+    assert w.sum() == one['ntrain'] and abs(first - one['losses'][0]) <= 2e-5 * one['losses'][0]
+    for res in (one, two[0], two[1]):
+        assert res['losses'][-1] < res['losses'][0]

@@ -50,10 +50,14 @@ def build_rank_graph(args, env):
     raw = synthetic.make_dataset(args.workload, seed=args.seed, device=dev, num_nodes=n, num_edges=e)
     raw = graph_utils.preprocess(args.workload, raw, 'GCN')
     nnz_total = raw['adj']._nnz()
-    _, parts = parted_coo_graph.partition_dict(raw, env.world_size)
-    mine = parts[env.rank]
+    rep = args.rep if args.model == 'GCN15D' else 1         # 1.5D: `rep` ranks share one row block
+    if env.world_size % (rep * rep):
+        raise SystemExit(f'GCN15D needs a world size that is a multiple of rep^2 = {rep * rep}')
+    nblocks, block = env.world_size // rep, env.rank // rep
+    _, parts = parted_coo_graph.partition_dict(raw, nblocks)
+    mine = parts[block]
     del raw, parts
-    g = coo_graph.Parted_COO_Graph(args.workload, env.rank, env.world_size, device=dev, attr_dict=mine)
+    g = coo_graph.Parted_COO_Graph(args.workload, block, nblocks, device=dev, attr_dict=mine)
     return g, n, nnz_total
 
 
@@ -116,7 +120,9 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the graph (debug only; invalidates the number)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU oracle work (0 = skip)')
-    ap.add_argument('--model', default='GCN', choices=['GCN', 'CachedGCN'])
+    ap.add_argument('--model', default='GCN', choices=['GCN', 'CachedGCN', 'AdaptiveGCN', 'GCN15D'],
+                    help='GCN is the headline; the others are the variants of BASELINE config 3')
+    ap.add_argument('--rep', type=int, default=2, help='replication factor c of GCN15D')
     ap.add_argument('--cache-input', action='store_true',
                     help='reuse the layer-1 input-feature blocks received in the first epoch (lossless; off for the headline number)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -126,6 +132,8 @@ def main():
                     help='opt-in A_hat (H W) ordering for layers with F_out < F_in (re-associated fp32; not the headline)')
     args = ap.parse_args()
     layers = args.layers or {'reddit': 2, 'products': 3, 'cora': 2}[args.workload]
+    if args.model in ('AdaptiveGCN', 'CachedGCN'):
+        layers = 2                                   # fixed two-layer models in the reference
 
     if os.environ.get('DGNN_FAULT_TIMEOUT'):       # debugging aid: dump every thread's stack and exit if stuck
         import faulthandler
@@ -154,13 +162,17 @@ def main():
 
     t_build = time.time()
     g, n_nodes, nnz_total = build_rank_graph(args, env)
-    model = dist_train.build_model(g, env, args.model, args.hidden, layers)
+    model = dist_train.build_model(g, env, args.model, args.hidden, layers, rep=args.rep)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
-    loss_func = torch.nn.CrossEntropyLoss()
+    loss_func = torch.nn.NLLLoss() if args.model == 'AdaptiveGCN' else torch.nn.CrossEntropyLoss()
+    epoch_no = [0]
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
     def step():
+        if hasattr(model, 'set_epoch'):
+            model.set_epoch(epoch_no[0])
+        epoch_no[0] += 1
         return dist_train.train_step(model, optimizer, loss_func, g, env)
 
     for _ in range(args.warmup):          # also builds the CSR blocks and work plans (once)
@@ -243,7 +255,7 @@ def main():
             "epoch_time_s": round(elapsed / args.steps, 6),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic (seeded R-MAT, {args.workload} shape, random-init torch.rand weights)",
-            "config": {"workload": f"{args.workload}-shape {layers}-layer GCN, hidden {args.hidden}, 1D row partition over {world} GPU(s)",
+            "config": {"workload": f"{args.workload}-shape {layers}-layer {args.model}, hidden {args.hidden}, 1D row partition over {world} GPU(s)",
                        "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
                        "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),
                        "scale": args.scale},

@@ -38,12 +38,18 @@ def evaluate(g, env, outputs, epoch):
     return res
 
 
-def build_model(g, env, model='GCN', hidden_dim=256, num_layers=3):
+def build_model(g, env, model='GCN', hidden_dim=256, num_layers=3, rep=2):
     if model == 'GCN':
         return GCN(g, env, hidden_dim=hidden_dim, num_layers=num_layers)
     if model == 'CachedGCN':
         return CachedGCN(g, env, hidden_dim=hidden_dim)
-    raise ValueError(f'unknown model {model!r} (GCN | CachedGCN)')
+    if model == 'AdaptiveGCN':       # 1D_CAGNET/dist_1d.py: 2 layers, log_softmax output (pair it with nll_loss)
+        from models import AdaptiveGCN
+        return AdaptiveGCN(g, env, hidden_dim=hidden_dim)
+    if model == 'GCN15D':            # 1D_CAGNET/dist_15d.py: g is row block rank // rep of world_size // rep
+        from models import GCN15D
+        return GCN15D(g, env, hidden_dim=hidden_dim, num_layers=num_layers, rep=rep)
+    raise ValueError(f'unknown model {model!r} (GCN | CachedGCN | AdaptiveGCN | GCN15D)')
 
 
 def train_step(model, optimizer, loss_func, g, env):

@@ -326,6 +326,12 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   for (int sb0 = kb; sb0 < ke; sb0 += SEGM) {
     const int se = min(sb0 + SEGM, ke);
     const int len = se - sb0;
+    if (len <= L) {                             // short run (sparse graphs): one entry per lane is all there is
+      const int kk = min(sb0 + li, se - 1);
+      const uint32_t c1 = (uint32_t)col[kk];
+      const float v1 = val[kk];
+      ent[li] = make_uint2(WIDE ? c1 : c1 * ldb_bytes, __float_as_uint(alpha * v1));
+    } else
 #pragma unroll 1
     for (int t0 = 0; t0 * L < len; t0 += 4) {   // 64 entries (8 loads per lane) in flight per trip
       uint32_t cx[4], vy[4];

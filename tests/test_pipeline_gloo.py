@@ -192,3 +192,77 @@ def test_cora_shape_two_ranks_equal_one_rank(tmp_path):
     assert w.sum() == one['ntrain'] and abs(first - one['losses'][0]) <= 2e-5 * one['losses'][0]
     for res in (one, two[0], two[1]):
         assert res['losses'][-1] < res['losses'][0]
+
+
+def _eight_worker(rank, world, port, log_dir, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.set_num_threads(1)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DGNN_LOG_DIR=log_dir)
+        import coo_graph
+        import dist_train
+        import dist_utils
+        from models import gcn
+        gcn.set_spmm_backend(_oracle_spmm, gather=_cpu_gather)
+        env = dist_utils.DistEnv(rank, world, 'gloo', echo=False)
+        full = coo_graph.COO_Graph('odd', attr_dict=_odd_graph())
+        g = coo_graph.Parted_COO_Graph('odd', rank, world, attr_dict=full.partition(world, save=False)[rank])
+        res = {'rows': g.local_num_nodes}
+        for mode in ('bcast', 'allgather', 'needed', 'auto'):
+            gcn._pipeline = gcn.StagePipeline(mode=mode, inflight=3, cache_input=False)
+            res[mode] = gcn.broadcast(g.adj_parts, g.features, 'ForwardL1').numpy()
+        gcn._pipeline = gcn.StagePipeline(mode='auto')
+        res['losses'] = dist_train.train(g, env, total_epoch=3, hidden_dim=16, num_layers=3, eval_every=2)
+        q.put((rank, res))
+        env.barrier_all()
+        torch.distributed.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+        raise e
+
+
+def _odd_graph():
+    g0 = torch.Generator().manual_seed(21)
+    n, e = 203, 1500                                    # 203 = 8 * 26 - 5: the last block is padded
+    return {"edge_index": torch.randint(0, n, (2, e), generator=g0), "features": torch.rand(n, 9, generator=g0),
+            "labels": torch.randint(0, 4, (n,), generator=g0), "train_mask": torch.rand(n, generator=g0) < 0.6,
+            "val_mask": torch.zeros(n, dtype=torch.bool), "test_mask": torch.zeros(n, dtype=torch.bool),
+            "num_nodes": n, "num_edges": e, "num_classes": 4}
+
+
+def test_eight_ranks_every_form_equals_the_unpartitioned_product(tmp_path):
+    """The world size the scaling run uses: 8 gloo ranks, a node count that does not divide (padding in the
+    last block), every exchange form. Each rank's rows equal the unpartitioned oracle product bit for bit."""
+    from oracle import ref_cpu
+    for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import coo_graph
+    full = coo_graph.COO_Graph('odd', attr_dict=_odd_graph())
+    adj = full.adj.coalesce()
+    n = full.num_nodes
+    want = np.zeros((n, 9), dtype=np.float32)
+    ref_cpu.spmm_coo(adj.indices()[0].numpy(), adj.indices()[1].numpy(), adj.values().numpy(), n, n,
+                     np.ascontiguousarray(full.features.numpy()), want, 1.0, 1.0)
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=400) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r, res in out.items():
+        assert 'error' not in res, res.get('error')
+    s = out[0]['rows']
+    assert s == 26
+    for mode in ('bcast', 'allgather', 'needed', 'auto'):
+        z = np.concatenate([out[r][mode] for r in range(world)])
+        assert z.shape[0] == s * world and np.array_equal(z[:n], want), mode
+        assert not z[n:].any()                                   # padding rows aggregate nothing
+    assert all(np.isfinite(out[r]['losses']).all() for r in range(world))

@@ -433,8 +433,11 @@ class StagePipeline:
         return (len(stages) == env.world_size > 1 and dist.get_world_size(group) == env.world_size
                 and all(src == blk for src, blk in stages) and len(adj_parts) == env.world_size)
 
-    def run(self, adj_parts, feat, tag, policy=None, group=None, stages=None):
+    def run(self, adj_parts, feat, tag, policy=None, group=None, stages=None, padded_out=False):
         """z = sum over stages of A[stage.block] @ H_(stage.src).
+
+        ``padded_out``: z may be a [s, F] view of a wider zero-padded buffer (for callers that only feed
+        it to matrix products, like DistGCNLayer); by default z is contiguous as in gcn.py:18.
 
         ``stages``: list of (src_rank, block_index) pairs, default [(j, j) for j in range(P)] -- the
         1D loop; the 1.5D variant passes the subset its replica owns and its column group.
@@ -451,8 +454,13 @@ class StagePipeline:
         # the root too as far as autograd can tell (gloo's CUDA path really does), and this tensor is often
         # saved for backward (a ReLU output). Its bits are never changed here.
         feat = orig.data
-        z = torch.zeros((adj_parts[stages[0][1]].size(0) if stages else feat.size(0), feat.size(1)),
-                        dtype=feat.dtype, device=feat.device)
+        rows = adj_parts[stages[0][1]].size(0) if stages else feat.size(0)
+        if padded_out and feat.is_cuda and _spmm_override is None and feat.size(1) % 32:
+            # rows of z on 128-byte lines: aligned float4 read-modify-write in the SpMM and an aligned
+            # leading dimension for the GEMM that consumes z; the caller sees the [s, F] view
+            z = torch.zeros((rows, (feat.size(1) + 31) // 32 * 32), dtype=feat.dtype, device=feat.device)[:, :feat.size(1)]
+        else:
+            z = torch.zeros((rows, feat.size(1)), dtype=feat.dtype, device=feat.device)
         plain = policy is None
         if plain and len(stages) == 1 and stages[0][0] == rank:
             with timer.timing_cuda('spmm'):
@@ -507,9 +515,9 @@ def transform_first():
     return os.environ.get('DGNN_TRANSFORM_FIRST', '0') == '1'
 
 
-def broadcast(local_adj_parts, local_feature, tag):
+def broadcast(local_adj_parts, local_feature, tag, padded_out=False):
     """z_loc = sum over src of A[rank, src] @ H_src  (new [s, F] tensor), gcn.py:16-30."""
-    return pipeline().run(local_adj_parts, local_feature, tag)
+    return pipeline().run(local_adj_parts, local_feature, tag, padded_out=padded_out)
 
 
 class DistGCNLayer(torch.autograd.Function):
@@ -532,7 +540,7 @@ class DistGCNLayer(torch.autograd.Function):
             with timer.timing_cuda('mm'):
                 hw = torch.mm(features, weight)
             return broadcast(adj_parts, hw, 'Forward' + tag + 'T')
-        z_local = broadcast(adj_parts, features, 'Forward' + tag)
+        z_local = broadcast(adj_parts, features, 'Forward' + tag, padded_out=True)
         with timer.timing_cuda('mm'):
             return torch.mm(z_local, weight)
 
@@ -540,7 +548,7 @@ class DistGCNLayer(torch.autograd.Function):
     def backward(ctx, grad_output):
         features, weight = ctx.saved_tensors
         blocks = getattr(ctx.adj_parts, 'transposed', None) or ctx.adj_parts
-        ag = broadcast(blocks, grad_output, 'Backward' + ctx.tag)
+        ag = broadcast(blocks, grad_output, 'Backward' + ctx.tag, padded_out=True)
         with DistEnv.env.timer.timing_cuda('mm'):
             # the input features of layer 1 need no gradient: skip that product (the reference computes
             # and discards it, gcn.py:49); every gradient that is used is unchanged

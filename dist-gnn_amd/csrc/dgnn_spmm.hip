@@ -254,6 +254,37 @@ __device__ __forceinline__ void c_store(float* p, int fbase, int F, f32x2 a01, f
   }
 }
 
+// One gather round: R entries of the group's LDS strip starting at j -> R rows of B in flight per lane,
+// then R fused multiply-adds per accumulator, in entry order.
+template <int R, bool WIDE>
+__device__ __forceinline__ void gather_round(const uint2* ent, int j, const char* Bbytes, uint32_t ldb_bytes,
+                                             uint32_t loff, f32x2& a01, f32x2& a23) {
+  uint2 e[R];
+  if constexpr (R == 1) {
+    e[0] = ent[j];
+  } else {
+#pragma unroll
+    for (int h = 0; h < R / 2; ++h) {                        // two entries per ds_read_b128
+      const uint4 t = *reinterpret_cast<const uint4*>(&ent[j + 2 * h]);
+      e[2 * h] = make_uint2(t.x, t.y);
+      e[2 * h + 1] = make_uint2(t.z, t.w);
+    }
+  }
+  float4 bb[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if constexpr (WIDE) bb[u] = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)e[u].x * ldb_bytes + loff));
+    else bb[u] = *reinterpret_cast<const float4*>(Bbytes + (e[u].x + loff));
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const float v = __uint_as_float(e[u].y);
+    const f32x2 vv = {v, v};
+    a01 = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01);
+    a23 = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23);
+  }
+}
+
 // Instruction budget of the inner loop (what bounds this kernel once gathers are L2-resident:
 // PMC showed TA 56 % busy, L2 latency 250 cycles, and the SIMDs saturated by ~14 VALU/LDS
 // instructions per gathered float4): a batch of 16 (col, val) entries is turned ONCE into
@@ -352,36 +383,13 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
     if (!gathers) continue;
     int j = 0;
 #pragma unroll 1
-    for (; j + U <= len; j += U) {
-      uint4 e[U / 2];
-#pragma unroll
-      for (int h = 0; h < U / 2; ++h) e[h] = *reinterpret_cast<const uint4*>(&ent[j + 2 * h]);
-      float4 bb[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t x = (u & 1) ? e[u / 2].z : e[u / 2].x;
-        if constexpr (WIDE) bb[u] = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)x * ldb_bytes + loff));
-        else bb[u] = *reinterpret_cast<const float4*>(Bbytes + (x + loff));
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float v = __uint_as_float((u & 1) ? e[u / 2].w : e[u / 2].y);
-        const f32x2 vv = {v, v};
-        a01 = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01);
-        a23 = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23);
-      }
-    }
+    for (; j + U <= len; j += U) gather_round<U, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);
+    // the leftover (< U entries) goes in rounds of 4, 2, 1: at most three memory latencies instead of one
+    // per entry -- on sparse graphs most runs ARE leftover
+    if constexpr (U > 4) if (j + 4 <= len) { gather_round<4, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 4; }
+    if constexpr (U > 2) if (j + 2 <= len) { gather_round<2, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 2; }
 #pragma unroll 1
-    for (; j < len; ++j) {
-      const uint2 e = ent[j];
-      float4 bb;
-      if constexpr (WIDE) bb = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)e.x * ldb_bytes + loff));
-      else bb = *reinterpret_cast<const float4*>(Bbytes + (e.x + loff));
-      const float v = __uint_as_float(e.y);
-      const f32x2 vv = {v, v};
-      a01 = __builtin_elementwise_fma(vv, (f32x2){bb.x, bb.y}, a01);
-      a23 = __builtin_elementwise_fma(vv, (f32x2){bb.z, bb.w}, a23);
-    }
+    for (; j < len; ++j) gather_round<1, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);   // one trip for U = 2, 4, 8
   }
 
   if (live) {
@@ -770,12 +778,18 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
       const bool narrow = (g_variant == 8);
       if (narrow)
         rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
-      else if (g_variant == 32 || (g_variant == 0 && ldb >= 256))   // 512-B slices: 3-9 % faster from 256 floats up
-        rc = launch_stage<32, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
-      else if (g_variant == 64)
-        rc = launch_stage<64, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
-      else
-        rc = launch_stage<16, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+      else {
+        // Gathers in flight per lane: 4 while one stage's slice of B fits the 256 MiB Infinity Cache, 2 when
+        // the rows come out of HBM (measured: products/papers shapes -6..-10 % with 2, Reddit -4 % with 4
+        // against the 8 of earlier rounds -- more outstanding random reads only queue up).
+        const int64_t stage_bytes = (int64_t)(m / plan->nstage + 1) * ldb * 4;
+        const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100 : (stage_bytes <= (256ll << 20) ? 4 : 2);
+        const bool wide_group = g_variant == 32 || (g_variant != 16 && ldb >= 256);   // 512-B slices from 256 floats up
+#define DGNN_LAUNCH(LL, UU) launch_stage<LL, UU>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s)
+        if (wide_group) rc = (u == 2) ? DGNN_LAUNCH(32, 2) : (u == 4) ? DGNN_LAUNCH(32, 4) : (u == 6) ? DGNN_LAUNCH(32, 6) : DGNN_LAUNCH(32, 8);
+        else rc = (u == 2) ? DGNN_LAUNCH(16, 2) : (u == 4) ? DGNN_LAUNCH(16, 4) : (u == 6) ? DGNN_LAUNCH(16, 6) : DGNN_LAUNCH(16, 8);
+#undef DGNN_LAUNCH
+      }
       if (rc != DGNN_OK) return rc;
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];

@@ -265,14 +265,14 @@ def default_stage_count(n, m, nnz, F):
     """Column-block stages for a block (measured on MI355X, sweeps on Reddit- and products-shaped blocks of
     the 1/2/4/8-rank partitions): enough stages that one 256-byte feature chunk of one column
     block is ~16 MiB of B (~32 MiB for blocks at most 64 floats wide, which run at the L2 gather ceiling out
-    of the Infinity Cache anyway), never so many that a (row, column block) run averages under ~16
+    of the Infinity Cache anyway), never so many that a (row, column block) run averages under ~24
     nonzeros, at most 16."""
     ld = padded_width(F)
     if n == 0 or nnz == 0:
         return 1
     budget = (16 << 20) if ld > 64 else (32 << 20)
     by_cache = -(-m * 256 // budget)
-    by_density = max(1, int(nnz / max(n, 1) / 16))
+    by_density = max(1, int(nnz / max(n, 1) / 24))
     return int(max(1, min(by_cache, by_density, 16)))
 
 

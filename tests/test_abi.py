@@ -45,6 +45,6 @@ def test_binding_rejects_cpu_tensors():
     assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 256) == 4
     assert spmm_cpp.default_stage_count(232965, 232965, 114848857, 41) == 2
     assert spmm_cpp.default_stage_count(29121, 29121, 1819992, 602) == 1          # a block of the 8-rank partition
-    assert spmm_cpp.default_stage_count(2449029, 2449029, 126167309, 100) == 3    # products: capped by run length
+    assert spmm_cpp.default_stage_count(2449029, 2449029, 126167309, 100) == 2    # products: capped by run length
     assert spmm_cpp.default_piece_len(114848857, 4) == 4096 and spmm_cpp.default_piece_len(1819992, 1) == 256
     assert spmm_cpp.default_piece_len(1000, 1) == 128

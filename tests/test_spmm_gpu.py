@@ -289,9 +289,9 @@ def test_gather_rows_is_an_exact_copy(F, ldd):
         spmm_cpp.gather_rows(dst, idx, dst)
 
 
-@pytest.mark.parametrize('variant', [2, 3, 8, 16, 32, 64])
+@pytest.mark.parametrize('variant', [2, 3, 8, 16, 32, 102, 106, 108])
 def test_kernel_variants_agree_bit_for_bit(variant):
-    """The A/B knobs (64-bit offsets, contiguous XCD shares, 8/16/32/64-lane groups) only change how the work
+    """The A/B knobs (64-bit offsets, contiguous XCD shares, 8/16/32-lane groups, 2/6/8 gathers in flight) only change how the work
     is laid out: same accumulation chain, so the same bits as the default dispatch."""
     import spmm_cpp
     rng = np.random.default_rng(77)

@@ -20,7 +20,11 @@ def process_wrapper(rank, args, func):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ['LOCAL_RANK'] = os.environ.get('LOCAL_RANK', str(rank))
     env = dist_utils.DistEnv(rank, args.nprocs, args.backend)
-    func(env, args)
+    try:
+        func(env, args)
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
 
 
 def parse_args(argv=None):

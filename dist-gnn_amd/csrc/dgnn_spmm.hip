@@ -331,9 +331,9 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   }
   const int64_t sidx = ((int64_t)sb * 4 + wave) * G + g;
   const int fbase = (chunk * L + li) * 4;
-  const bool live = sidx < nseg;
-  int4 s = make_int4(0, 0, 0, -1);             // {row, k0, k1, out}: out < 0 -> accumulate into C[row]
-  if (live) s = seg[sidx];
+  int4 s = make_int4(-1, 0, 0, -1);            // {row, k0, k1, out}: out < 0 -> accumulate into C[row]
+  if (sidx < nseg) s = seg[sidx];
+  const bool live = s.x >= 0;                   // row -1: an unused slot of a list sized by an upper bound
   const int kb = s.y, ke = s.z;
   const bool direct = s.w < 0;
   // lanes past the padded width gather a valid float4 (the row's last one) and never store it
@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) void merge_kernel(
   const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (run >= ncut) return;
   const int4 c4 = cut[run];                    // {row, pbase, count, -}
+  if (c4.z <= 0) return;                        // unused slot (list sized by an upper bound)
   const int lane = threadIdx.x & 63;
   for (int f = lane * 4; f < F; f += 256) {
     float* c = C + (int64_t)c4.x * ldc + f;
@@ -506,12 +507,83 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
-// One uncut segment per row, in row order: the work list of the stage kernel for a block nobody planned.
-__global__ __launch_bounds__(256) void rows_plan_kernel(const int32_t* __restrict__ rowptr, int32_t n,
-                                                        int4* __restrict__ seg) {
+// Work list of the stage kernel for a block nobody planned, built on the device in three small passes over
+// the rows: one segment per row, rows longer than `piece` cut into pieces (-> partial rows -> merge, as in
+// a host-built plan), everything grouped by length class (bit length of the run), longest class first --
+// long runs start early and the runs that share a wave have similar lengths. The lists are sized by upper
+// bounds (the host never learns the counts): unused segment slots keep row = -1, unused cut slots count = 0.
+// `cnt` is 128 ints: [0, 32) class counts, [32, 64) write cursors, [64] cut rows, [65] partial rows.
+// Positions come from atomic counters, so the list order varies from run to run; the result does not
+// (a row, or a piece, is one chain with one writer; pieces are merged in piece order).
+__device__ __forceinline__ int len_class(int len) { return len <= 0 ? 0 : 32 - __clz(len); }
+
+__global__ __launch_bounds__(256) void rows_hist_kernel(const int32_t* __restrict__ rowptr, int32_t n, int piece,
+                                                        int* __restrict__ cnt) {
+  __shared__ int local[32];
+  if (threadIdx.x < 32) local[threadIdx.x] = 0;
+  __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    seg[i] = make_int4((int)i, rowptr[i], rowptr[i + 1], -1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int len = rowptr[i + 1] - rowptr[i];
+    if (len <= piece) {
+      atomicAdd(&local[len_class(len)], 1);
+    } else {
+      const int full = len / piece, rem = len - full * piece;
+      atomicAdd(&local[len_class(piece)], full);
+      if (rem) atomicAdd(&local[len_class(rem)], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 && local[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], local[threadIdx.x]);
+}
+
+__global__ void rows_cursor_kernel(int* __restrict__ cnt) {
+  if (threadIdx.x == 0) {
+    int at = 0;
+    for (int c = 31; c >= 0; --c) { cnt[32 + c] = at; at += cnt[c]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_plan_kernel(const int32_t* __restrict__ rowptr, int32_t n, int piece,
+                                                        int* __restrict__ cnt, int4* __restrict__ seg,
+                                                        int4* __restrict__ cut, bool natural) {
+  // A tile of 256 rows ranks its uncut rows per class in LDS and reserves its slots with one global atomic
+  // per class (2.4 M rows hammering 32 global counters one by one cost more than the SpMM itself).
+  __shared__ int lcnt[32], lbase[32];
+  for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < n; t0 += (int64_t)gridDim.x * 256) {
+    if (threadIdx.x < 32) lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = t0 + threadIdx.x;
+    const bool valid = i < n;
+    const int k0 = valid ? rowptr[i] : 0, k1 = valid ? rowptr[i + 1] : 0, len = k1 - k0;
+    const bool whole = valid && (len <= piece || natural);
+    const int cls = len_class(len);
+    int rank = 0;
+    if (whole && !natural) rank = atomicAdd(&lcnt[cls], 1);
+    __syncthreads();
+    if (threadIdx.x < 32 && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&cnt[32 + threadIdx.x], lcnt[threadIdx.x]);
+    __syncthreads();
+    if (whole) {
+      seg[natural ? (int)i : lbase[cls] + rank] = make_int4((int)i, k0, k1, -1);
+    } else if (valid) {
+      const int np = (len + piece - 1) / piece;
+      const int pbase = atomicAdd(&cnt[65], np);
+      cut[atomicAdd(&cnt[64], 1)] = make_int4((int)i, pbase, np, 0);
+      for (int p = 0; p < np; ++p) {
+        const int a = k0 + p * piece, b = min(a + piece, k1);
+        seg[atomicAdd(&cnt[32 + len_class(b - a)], 1)] = make_int4((int)i, a, b, pbase + p);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Piece length of a device-built plan: the rule of spmm_cpp.default_piece_len (one stage).
+int auto_piece_len(int64_t nnz) {
+  const double want = (double)nnz / 7000.0;
+  int p = 128;
+  while (p * 1.41 < want && p < 4096) p *= 2;
+  return p;
 }
 
 unsigned capped_blocks(int64_t work, unsigned cap) {
@@ -719,22 +791,45 @@ int dgnn_spmm_coo_f32(const int32_t* row, const int32_t* col, const float* val,
   return dgnn_spmm_csr_f32(rowptr_ws, col, val, n, m, nnz, B, ldb, C, ldc, F, alpha, beta, stream);
 }
 
+int dgnn_coo_aligned_workspace(int32_t n, int64_t nnz, int64_t* plan_ws_ints, int64_t* partial_rows) {
+  if (n < 0 || nnz < 0 || !plan_ws_ints || !partial_rows) return fail(DGNN_E_BADARG, "coo_aligned_workspace: bad argument%s", "");
+  const int64_t piece = auto_piece_len(nnz);
+  const int64_t ncut_max = nnz / piece + 1, nseg_max = (int64_t)n + nnz / piece + 1;
+  *plan_ws_ints = 128 + 4 * nseg_max + 4 * ncut_max;
+  *partial_rows = 2 * (nnz / piece) + 2;
+  return DGNN_OK;
+}
+
 int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const float* val,
-                              int32_t n, int32_t m, int64_t nnz, int32_t* rowptr_ws, int32_t* seg_ws,
-                              const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                              int32_t n, int32_t m, int64_t nnz, int32_t* rowptr_ws, int32_t* plan_ws,
+                              const float* B, int64_t ldb, float* C, int64_t ldc,
+                              float* partial, int64_t ldp, int32_t F,
                               float alpha, float beta, void* stream) {
   if (n == 0 || F == 0) return DGNN_OK;
-  if (!seg_ws || !aligned(seg_ws, 16)) return fail(DGNN_E_BADARG, "spmm_coo_aligned: seg_ws must be a 16-byte aligned int32[4n]%s", "");
+  if (!plan_ws || !aligned(plan_ws, 16)) return fail(DGNN_E_BADARG, "spmm_coo_aligned: plan_ws must be 16-byte aligned%s", "");
+  const int piece = (g_variant == 5) ? 0x7fffffff : auto_piece_len(nnz);
+  const int64_t ncut_max = nnz / auto_piece_len(nnz) + 1, nseg_max = (int64_t)n + nnz / auto_piece_len(nnz) + 1;
+  if (nseg_max > 0x7fffffffLL) return fail(DGNN_E_BADARG, "spmm_coo_aligned: block too large%s", "");
   int rc = dgnn_coo2csr_i32(row, nnz, n, rowptr_ws, stream);
   if (rc != DGNN_OK) return rc;
-  hipLaunchKernelGGL(rows_plan_kernel, dim3(capped_blocks(n, 4096)), dim3(256), 0, (hipStream_t)stream,
-                     rowptr_ws, n, reinterpret_cast<int4*>(seg_ws));
+  hipStream_t s = (hipStream_t)stream;
+  int* cnt = plan_ws;
+  int4* seg = reinterpret_cast<int4*>(plan_ws + 128);
+  int4* cut = seg + nseg_max;
+  DGNN_HIP(hipMemsetAsync(cnt, 0, 128 * sizeof(int), s));
+  DGNN_HIP(hipMemsetAsync(seg, 0xff, (size_t)nseg_max * sizeof(int4), s));     // row = -1: unused slot
+  DGNN_HIP(hipMemsetAsync(cut, 0, (size_t)ncut_max * sizeof(int4), s));        // count = 0: unused slot
+  hipLaunchKernelGGL(rows_hist_kernel, dim3(capped_blocks(n, 1024)), dim3(256), 0, s, rowptr_ws, n, piece, cnt);
+  hipLaunchKernelGGL(rows_cursor_kernel, dim3(1), dim3(64), 0, s, cnt);
+  hipLaunchKernelGGL(rows_plan_kernel, dim3(capped_blocks(n, 4096)), dim3(256), 0, s, rowptr_ws, n, piece, cnt,
+                     seg, cut, g_variant == 5);
   DGNN_HIP(hipGetLastError());
-  const int64_t seg_off[2] = {0, n}, cut_off[2] = {0, 0};
+  const int64_t seg_off[2] = {0, nseg_max}, cut_off[2] = {0, ncut_max};
   dgnn_plan plan;
-  plan.nstage = 1; plan.seg = seg_ws; plan.stage_seg_off = seg_off; plan.cut = nullptr;
-  plan.stage_cut_off = cut_off; plan.npartial = 0; plan.max_seg_len = 0x7fffffff;
-  return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, nullptr, 0, F, alpha, beta, stream);
+  plan.nstage = 1; plan.seg = reinterpret_cast<const int32_t*>(seg); plan.stage_seg_off = seg_off;
+  plan.cut = reinterpret_cast<const int32_t*>(cut); plan.stage_cut_off = cut_off;
+  plan.npartial = 2 * (nnz / auto_piece_len(nnz)) + 2; plan.max_seg_len = piece;
+  return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
 }
 
 int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
@@ -783,7 +878,10 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
         // the rows come out of HBM (measured: products/papers shapes -6..-10 % with 2, Reddit -4 % with 4
         // against the 8 of earlier rounds -- more outstanding random reads only queue up).
         const int64_t stage_bytes = (int64_t)(m / plan->nstage + 1) * ldb * 4;
-        const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100 : (stage_bytes <= (256ll << 20) ? 4 : 2);
+        // A plan that leaves very long runs whole (the plan-less reference call) is bound by the serial walk
+        // of its longest run: there, 8 in flight.
+        const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100
+                      : plan->max_seg_len > 16384 ? 8 : (stage_bytes <= (256ll << 20) ? 4 : 2);
         const bool wide_group = g_variant == 32 || (g_variant != 16 && ldb >= 256);   // 512-B slices from 256 floats up
 #define DGNN_LAUNCH(LL, UU) launch_stage<LL, UU>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s)
         if (wide_group) rc = (u == 2) ? DGNN_LAUNCH(32, 2) : (u == 4) ? DGNN_LAUNCH(32, 4) : (u == 6) ? DGNN_LAUNCH(32, 6) : DGNN_LAUNCH(32, 8);

@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--beta', type=float, default=1.0)
     ap.add_argument('--torch-ref', action='store_true')
     ap.add_argument('--plan-variants', default='0')
+    ap.add_argument('--drop-in-variant', type=int, default=0)
     ap.add_argument('--drop-in', action='store_true', help='also time the reference-signature call spmm_cusparse(row, col, val, ...)')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
     args = ap.parse_args()
@@ -87,6 +88,7 @@ def main():
         if args.drop_in:
             ci = adj.indices()
             r32, c32, vv = ci[0].int(), ci[1].int(), adj.values()
+            spmm_cpp.set_variant(args.drop_in_variant)
             C.zero_()
             spmm_cpp.spmm_csr(A, B, C, 1.0, 0.0)
             Cd = torch.full_like(C, float('nan'))

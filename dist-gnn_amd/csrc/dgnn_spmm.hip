@@ -507,83 +507,148 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
-// Work list of the stage kernel for a block nobody planned, built on the device in three small passes over
-// the rows: one segment per row, rows longer than `piece` cut into pieces (-> partial rows -> merge, as in
-// a host-built plan), everything grouped by length class (bit length of the run), longest class first --
-// long runs start early and the runs that share a wave have similar lengths. The lists are sized by upper
-// bounds (the host never learns the counts): unused segment slots keep row = -1, unused cut slots count = 0.
-// `cnt` is 128 ints: [0, 32) class counts, [32, 64) write cursors, [64] cut rows, [65] partial rows.
-// Positions come from atomic counters, so the list order varies from run to run; the result does not
-// (a row, or a piece, is one chain with one writer; pieces are merged in piece order).
+// Work plan of the stage kernel for a block nobody planned, built on the device in three small passes over
+// the rows -- the same plan shape a host-built dgnn_plan has: `ns` column-block stages; per stage one
+// segment per non-empty (row, column block) run, runs longer than `piece` cut into pieces (-> partial rows
+// -> merge); inside a stage everything grouped by length class (bit length of the run), longest class
+// first, so long runs start early and the runs that share a wave have similar lengths. The lists are
+// sized by upper bounds (the host never learns the counts): unused segment slots keep row = -1, unused
+// cut slots count = 0. Header `hdr`: per stage PLAN_HDR_STAGE ints = [0, 32) class counts, [32, 64) write
+// cursors, [64] cut runs; then [PLAN_HDR_NPART] partial rows. Positions come from atomic counters, so the
+// list order varies from run to run; the result does not (a run, or a piece, is one chain with one
+// writer; pieces are merged in piece order).
+constexpr int PLAN_MAX_STAGES = 16;
+constexpr int PLAN_HDR_STAGE = 80;
+constexpr int PLAN_HDR_NPART = PLAN_MAX_STAGES * PLAN_HDR_STAGE;
+constexpr int PLAN_HDR_INTS = PLAN_HDR_NPART + 16;
+
 __device__ __forceinline__ int len_class(int len) { return len <= 0 ? 0 : 32 - __clz(len); }
 
-__global__ __launch_bounds__(256) void rows_hist_kernel(const int32_t* __restrict__ rowptr, int32_t n, int piece,
-                                                        int* __restrict__ cnt) {
-  __shared__ int local[32];
-  if (threadIdx.x < 32) local[threadIdx.x] = 0;
+// first position in [lo, hi) whose column is >= bound (columns of a row ascend)
+__device__ __forceinline__ int col_lower_bound(const int32_t* __restrict__ col, int lo, int hi, int bound) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < bound) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void plan_hist_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                        int32_t n, int ns, int cbw, int piece, int* __restrict__ hdr) {
+  __shared__ int local[PLAN_MAX_STAGES][32];
+  for (int t = threadIdx.x; t < ns * 32; t += 256) local[t >> 5][t & 31] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int len = rowptr[i + 1] - rowptr[i];
-    if (len <= piece) {
-      atomicAdd(&local[len_class(len)], 1);
-    } else {
-      const int full = len / piece, rem = len - full * piece;
-      atomicAdd(&local[len_class(piece)], full);
-      if (rem) atomicAdd(&local[len_class(rem)], 1);
+    int a = rowptr[i];
+    const int k1 = rowptr[i + 1];
+    for (int st = 0; st < ns && a < k1; ++st) {
+      const int b = (st == ns - 1) ? k1 : col_lower_bound(col, a, k1, (st + 1) * cbw);
+      const int len = b - a;
+      if (len > 0 && len <= piece) {
+        atomicAdd(&local[st][len_class(len)], 1);
+      } else if (len > piece) {
+        const int full = len / piece, rem = len - full * piece;
+        atomicAdd(&local[st][len_class(piece)], full);
+        if (rem) atomicAdd(&local[st][len_class(rem)], 1);
+      }
+      a = b;
     }
   }
   __syncthreads();
-  if (threadIdx.x < 32 && local[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], local[threadIdx.x]);
+  for (int t = threadIdx.x; t < ns * 32; t += 256)
+    if (local[t >> 5][t & 31]) atomicAdd(&hdr[(t >> 5) * PLAN_HDR_STAGE + (t & 31)], local[t >> 5][t & 31]);
 }
 
-__global__ void rows_cursor_kernel(int* __restrict__ cnt) {
-  if (threadIdx.x == 0) {
+__global__ void plan_cursor_kernel(int* __restrict__ hdr, int ns) {
+  const int st = threadIdx.x;
+  if (st < ns) {
+    int* h = hdr + st * PLAN_HDR_STAGE;
     int at = 0;
-    for (int c = 31; c >= 0; --c) { cnt[32 + c] = at; at += cnt[c]; }
+    for (int c = 31; c >= 0; --c) { h[32 + c] = at; at += h[c]; }
   }
 }
 
-__global__ __launch_bounds__(256) void rows_plan_kernel(const int32_t* __restrict__ rowptr, int32_t n, int piece,
-                                                        int* __restrict__ cnt, int4* __restrict__ seg,
-                                                        int4* __restrict__ cut, bool natural) {
-  // A tile of 256 rows ranks its uncut rows per class in LDS and reserves its slots with one global atomic
-  // per class (2.4 M rows hammering 32 global counters one by one cost more than the SpMM itself).
-  __shared__ int lcnt[32], lbase[32];
+__global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                        int32_t n, int ns, int cbw, int piece, int* __restrict__ hdr,
+                                                        int4* __restrict__ seg, int64_t seg_stride,
+                                                        int4* __restrict__ cut, int64_t cut_stride) {
+  // A tile of 256 rows ranks its uncut runs per (stage, class) in LDS and reserves their slots with one
+  // global atomic per (stage, class): millions of rows hammering a few global counters one by one cost
+  // more than the SpMM itself.
+  __shared__ int lcnt[PLAN_MAX_STAGES][32], lbase[PLAN_MAX_STAGES][32];
+  __shared__ int lend[PLAN_MAX_STAGES][256];                 // end of the run of (stage, thread)
+  __shared__ unsigned short lrank[PLAN_MAX_STAGES][256];
   for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < n; t0 += (int64_t)gridDim.x * 256) {
-    if (threadIdx.x < 32) lcnt[threadIdx.x] = 0;
+    for (int t = threadIdx.x; t < ns * 32; t += 256) lcnt[t >> 5][t & 31] = 0;
     __syncthreads();
     const int64_t i = t0 + threadIdx.x;
     const bool valid = i < n;
-    const int k0 = valid ? rowptr[i] : 0, k1 = valid ? rowptr[i + 1] : 0, len = k1 - k0;
-    const bool whole = valid && (len <= piece || natural);
-    const int cls = len_class(len);
-    int rank = 0;
-    if (whole && !natural) rank = atomicAdd(&lcnt[cls], 1);
+    const int k0 = valid ? rowptr[i] : 0, k1 = valid ? rowptr[i + 1] : 0;
+    int a = k0;
+    for (int st = 0; st < ns; ++st) {
+      const int b = (a >= k1) ? k1 : (st == ns - 1) ? k1 : col_lower_bound(col, a, k1, (st + 1) * cbw);
+      lend[st][threadIdx.x] = b;
+      const int len = b - a;
+      if (len > 0 && len <= piece) lrank[st][threadIdx.x] = (unsigned short)atomicAdd(&lcnt[st][len_class(len)], 1);
+      a = b;
+    }
     __syncthreads();
-    if (threadIdx.x < 32 && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&cnt[32 + threadIdx.x], lcnt[threadIdx.x]);
+    for (int t = threadIdx.x; t < ns * 32; t += 256)
+      if (lcnt[t >> 5][t & 31]) lbase[t >> 5][t & 31] = atomicAdd(&hdr[(t >> 5) * PLAN_HDR_STAGE + 32 + (t & 31)], lcnt[t >> 5][t & 31]);
     __syncthreads();
-    if (whole) {
-      seg[natural ? (int)i : lbase[cls] + rank] = make_int4((int)i, k0, k1, -1);
-    } else if (valid) {
-      const int np = (len + piece - 1) / piece;
-      const int pbase = atomicAdd(&cnt[65], np);
-      cut[atomicAdd(&cnt[64], 1)] = make_int4((int)i, pbase, np, 0);
-      for (int p = 0; p < np; ++p) {
-        const int a = k0 + p * piece, b = min(a + piece, k1);
-        seg[atomicAdd(&cnt[32 + len_class(b - a)], 1)] = make_int4((int)i, a, b, pbase + p);
+    a = k0;
+    for (int st = 0; st < ns; ++st) {
+      const int b = lend[st][threadIdx.x];
+      const int len = b - a;
+      int4* const sseg = seg + st * seg_stride;
+      if (len > 0 && len <= piece) {
+        sseg[lbase[st][len_class(len)] + lrank[st][threadIdx.x]] = make_int4((int)i, a, b, -1);
+      } else if (len > piece) {
+        int* const h = hdr + st * PLAN_HDR_STAGE;
+        const int np = (len + piece - 1) / piece;
+        const int pbase = atomicAdd(&hdr[PLAN_HDR_NPART], np);
+        cut[st * cut_stride + atomicAdd(&h[64], 1)] = make_int4((int)i, pbase, np, 0);
+        for (int p = 0; p < np; ++p) {
+          const int pa = a + p * piece, pb = min(pa + piece, b);
+          sseg[atomicAdd(&h[32 + len_class(pb - pa)], 1)] = make_int4((int)i, pa, pb, pbase + p);
+        }
       }
+      a = b;
     }
     __syncthreads();
   }
 }
 
-// Piece length of a device-built plan: the rule of spmm_cpp.default_piece_len (one stage).
-int auto_piece_len(int64_t nnz) {
-  const double want = (double)nnz / 7000.0;
+// The host-side rules of spmm_cpp (default_stage_count, default_piece_len), for plans built here.
+int auto_stage_count(int64_t n, int64_t m, int64_t nnz, int64_t ldb) {
+  if (n <= 0 || nnz <= 0) return 1;
+  const int64_t budget = (ldb > 64) ? (16ll << 20) : (32ll << 20);
+  const int64_t by_cache = (m * 256 + budget - 1) / budget;
+  const int64_t by_density = nnz / n / 24 > 1 ? nnz / n / 24 : 1;
+  int64_t ns = by_cache < by_density ? by_cache : by_density;
+  if (ns > PLAN_MAX_STAGES) ns = PLAN_MAX_STAGES;
+  return ns < 1 ? 1 : (int)ns;
+}
+
+int auto_piece_len(int64_t nnz_per_stage) {
+  const double want = (double)nnz_per_stage / 7000.0;
   int p = 128;
   while (p * 1.41 < want && p < 4096) p *= 2;
   return p;
+}
+
+struct DevicePlanShape { int ns, piece; int64_t nseg_max, ncut_max, npartial_max, ws_ints; };
+
+DevicePlanShape device_plan_shape(int64_t n, int64_t m, int64_t nnz, int64_t ldb) {
+  DevicePlanShape d;
+  d.ns = auto_stage_count(n, m, nnz, ldb);
+  d.piece = auto_piece_len(nnz / d.ns);
+  d.ncut_max = nnz / d.piece + 1;                            // per stage
+  d.nseg_max = n + nnz / d.piece + 1;                        // per stage
+  d.npartial_max = 2 * (nnz / d.piece) + 2 * d.ns + 2;
+  d.ws_ints = PLAN_HDR_INTS + 4 * d.ns * (d.nseg_max + d.ncut_max);
+  return d;
 }
 
 unsigned capped_blocks(int64_t work, unsigned cap) {
@@ -791,12 +856,11 @@ int dgnn_spmm_coo_f32(const int32_t* row, const int32_t* col, const float* val,
   return dgnn_spmm_csr_f32(rowptr_ws, col, val, n, m, nnz, B, ldb, C, ldc, F, alpha, beta, stream);
 }
 
-int dgnn_coo_aligned_workspace(int32_t n, int64_t nnz, int64_t* plan_ws_ints, int64_t* partial_rows) {
-  if (n < 0 || nnz < 0 || !plan_ws_ints || !partial_rows) return fail(DGNN_E_BADARG, "coo_aligned_workspace: bad argument%s", "");
-  const int64_t piece = auto_piece_len(nnz);
-  const int64_t ncut_max = nnz / piece + 1, nseg_max = (int64_t)n + nnz / piece + 1;
-  *plan_ws_ints = 128 + 4 * nseg_max + 4 * ncut_max;
-  *partial_rows = 2 * (nnz / piece) + 2;
+int dgnn_coo_aligned_workspace(int32_t n, int32_t m, int64_t nnz, int64_t ldb, int64_t* plan_ws_ints, int64_t* partial_rows) {
+  if (n < 0 || m < 0 || nnz < 0 || !plan_ws_ints || !partial_rows) return fail(DGNN_E_BADARG, "coo_aligned_workspace: bad argument%s", "");
+  const DevicePlanShape d = device_plan_shape(n, m, nnz, ldb);
+  *plan_ws_ints = d.ws_ints;
+  *partial_rows = d.npartial_max;
   return DGNN_OK;
 }
 
@@ -807,28 +871,29 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
                               float alpha, float beta, void* stream) {
   if (n == 0 || F == 0) return DGNN_OK;
   if (!plan_ws || !aligned(plan_ws, 16)) return fail(DGNN_E_BADARG, "spmm_coo_aligned: plan_ws must be 16-byte aligned%s", "");
-  const int piece = (g_variant == 5) ? 0x7fffffff : auto_piece_len(nnz);
-  const int64_t ncut_max = nnz / auto_piece_len(nnz) + 1, nseg_max = (int64_t)n + nnz / auto_piece_len(nnz) + 1;
-  if (nseg_max > 0x7fffffffLL) return fail(DGNN_E_BADARG, "spmm_coo_aligned: block too large%s", "");
+  const DevicePlanShape d = device_plan_shape(n, m, nnz, ldb);
+  if (d.nseg_max > 0x7fffffffLL) return fail(DGNN_E_BADARG, "spmm_coo_aligned: block too large%s", "");
   int rc = dgnn_coo2csr_i32(row, nnz, n, rowptr_ws, stream);
   if (rc != DGNN_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  int* cnt = plan_ws;
-  int4* seg = reinterpret_cast<int4*>(plan_ws + 128);
-  int4* cut = seg + nseg_max;
-  DGNN_HIP(hipMemsetAsync(cnt, 0, 128 * sizeof(int), s));
-  DGNN_HIP(hipMemsetAsync(seg, 0xff, (size_t)nseg_max * sizeof(int4), s));     // row = -1: unused slot
-  DGNN_HIP(hipMemsetAsync(cut, 0, (size_t)ncut_max * sizeof(int4), s));        // count = 0: unused slot
-  hipLaunchKernelGGL(rows_hist_kernel, dim3(capped_blocks(n, 1024)), dim3(256), 0, s, rowptr_ws, n, piece, cnt);
-  hipLaunchKernelGGL(rows_cursor_kernel, dim3(1), dim3(64), 0, s, cnt);
-  hipLaunchKernelGGL(rows_plan_kernel, dim3(capped_blocks(n, 4096)), dim3(256), 0, s, rowptr_ws, n, piece, cnt,
-                     seg, cut, g_variant == 5);
+  int* hdr = plan_ws;
+  int4* seg = reinterpret_cast<int4*>(plan_ws + PLAN_HDR_INTS);
+  int4* cut = seg + d.ns * d.nseg_max;
+  const int cbw = (int)((m + d.ns - 1) / d.ns);
+  DGNN_HIP(hipMemsetAsync(hdr, 0, PLAN_HDR_INTS * sizeof(int), s));
+  DGNN_HIP(hipMemsetAsync(seg, 0xff, (size_t)(d.ns * d.nseg_max) * sizeof(int4), s));   // row = -1: unused slot
+  DGNN_HIP(hipMemsetAsync(cut, 0, (size_t)(d.ns * d.ncut_max) * sizeof(int4), s));      // count = 0: unused slot
+  hipLaunchKernelGGL(plan_hist_kernel, dim3(capped_blocks(n, 1024)), dim3(256), 0, s, rowptr_ws, col, n, d.ns, cbw, d.piece, hdr);
+  hipLaunchKernelGGL(plan_cursor_kernel, dim3(1), dim3(64), 0, s, hdr, d.ns);
+  hipLaunchKernelGGL(plan_fill_kernel, dim3(capped_blocks(n, 4096)), dim3(256), 0, s, rowptr_ws, col, n, d.ns, cbw, d.piece,
+                     hdr, seg, d.nseg_max, cut, d.ncut_max);
   DGNN_HIP(hipGetLastError());
-  const int64_t seg_off[2] = {0, nseg_max}, cut_off[2] = {0, ncut_max};
+  int64_t seg_off[PLAN_MAX_STAGES + 1], cut_off[PLAN_MAX_STAGES + 1];
+  for (int st = 0; st <= d.ns; ++st) { seg_off[st] = st * d.nseg_max; cut_off[st] = st * d.ncut_max; }
   dgnn_plan plan;
-  plan.nstage = 1; plan.seg = reinterpret_cast<const int32_t*>(seg); plan.stage_seg_off = seg_off;
+  plan.nstage = d.ns; plan.seg = reinterpret_cast<const int32_t*>(seg); plan.stage_seg_off = seg_off;
   plan.cut = reinterpret_cast<const int32_t*>(cut); plan.stage_cut_off = cut_off;
-  plan.npartial = 2 * (nnz / auto_piece_len(nnz)) + 2; plan.max_seg_len = piece;
+  plan.npartial = d.npartial_max; plan.max_seg_len = d.piece;
   return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
 }
 

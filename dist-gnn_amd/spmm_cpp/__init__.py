@@ -123,9 +123,9 @@ def spmm_cusparse(A_row_idx, A_col_idx, A_values, A_row, A_col, B, C, alpha, bet
             # big enough to pay for a padded copy of B: the staged kernel on a one-run-per-row work list
             Bp = B if (ldb % 4 == 0 and B.data_ptr() % 16 == 0) else pad_rows(B, _pad_buffer(m, padded_width(F), B.device))
             ws_ints, prow = ctypes.c_int64(), ctypes.c_int64()
-            _check(_lib.dgnn_coo_aligned_workspace(n, nnz, ctypes.byref(ws_ints), ctypes.byref(prow)), 'coo_aligned_workspace')
-            plan_ws = _scratch('plan', ws_ints.value, torch.int32, C.device)
             ldp = Bp.stride(0)
+            _check(_lib.dgnn_coo_aligned_workspace(n, m, nnz, ldp, ctypes.byref(ws_ints), ctypes.byref(prow)), 'coo_aligned_workspace')
+            plan_ws = _scratch('plan', ws_ints.value, torch.int32, C.device)
             partial = _scratch('partial', prow.value * ldp, torch.float32, C.device)
             rc = _lib.dgnn_spmm_coo_aligned_f32(A_row_idx.data_ptr(), A_col_idx.data_ptr(), A_values.data_ptr(),
                                                 n, m, nnz, ws.data_ptr(), plan_ws.data_ptr(), Bp.data_ptr(), ldp,
@@ -250,7 +250,7 @@ def pad_rows(src, dst=None):
 
 
 _lib.dgnn_spmm_coo_aligned_f32.argtypes = [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p]
-_lib.dgnn_coo_aligned_workspace.argtypes = [_i32, _i64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+_lib.dgnn_coo_aligned_workspace.argtypes = [_i32, _i32, _i64, _i64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
 _lib.dgnn_coo_aligned_workspace.restype = ctypes.c_int
 _lib.dgnn_spmm_coo_aligned_f32.restype = ctypes.c_int
 _lib.dgnn_gather_rows_f32.argtypes = [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]

@@ -149,8 +149,9 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
 /*
  * spmm_cusparse's operand list (row-sorted COO, spmm.cpp:16-17) on the fast kernel, for callers that hand
  * over a fresh COO every call as the reference's models do (gcn.py:11) and so cannot keep a plan: a
- * one-stage work plan is built on the stream, on the device (rows grouped by length class, longest first;
- * rows longer than the piece length cut and merged as in dgnn_spmm_plan_f32). No host synchronisation: the
+ * work plan is built on the stream, on the device (column-block stages; per stage the runs grouped by
+ * length class, longest first; runs longer than the piece length cut and merged as in
+ * dgnn_spmm_plan_f32). No host synchronisation: the
  * lists and the partial buffer are sized by upper bounds that dgnn_coo_aligned_workspace reports.
  * Uncut rows carry the bits of dgnn_spmm_coo_f32; cut rows the fixed-order piece sums.
  *   B           ldb % 4 == 0, 16-byte aligned base (dgnn_pad_rows_f32)
@@ -158,7 +159,8 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
  *   plan_ws     int32[plan_ws_ints] workspace, 16-byte aligned
  *   partial     float[partial_rows * ldp] workspace, ldp >= ldb, ldp % 4 == 0, 16-byte aligned
  */
-int dgnn_coo_aligned_workspace(int32_t n, int64_t nnz, int64_t* plan_ws_ints, int64_t* partial_rows);
+int dgnn_coo_aligned_workspace(int32_t n, int32_t m, int64_t nnz, int64_t ldb,
+                               int64_t* plan_ws_ints, int64_t* partial_rows);
 int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const float* val,
                               int32_t n, int32_t m, int64_t nnz, int32_t* rowptr_ws, int32_t* plan_ws,
                               const float* B, int64_t ldb, float* C, int64_t ldc,

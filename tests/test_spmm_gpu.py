@@ -340,7 +340,8 @@ def test_feature_blocks_beyond_4_gib_use_wide_offsets():
 
 
 @pytest.mark.parametrize('n,m,nnz,F,alpha,beta', [(2500, 2500, 150000, 602, 1.0, 1.0), (4000, 1500, 90000, 256, 1.0, 0.0),
-                                                  (1200, 5000, 120000, 41, 0.5, 2.0), (3000, 3000, 80000, 100, -1.0, 1.0)])
+                                                  (1200, 5000, 120000, 41, 0.5, 2.0), (3000, 3000, 80000, 100, -1.0, 1.0),
+                                                  (3000, 140000, 200000, 64, 1.0, 1.0)])     # wide enough for 2 column stages
 def test_reference_signature_takes_the_fast_kernel_without_a_plan(n, m, nnz, F, alpha, beta):
     """spmm_cusparse(row, col, val, ...) with enough nonzeros runs the staged kernel on a work plan built on the
     device (dgnn_spmm_coo_aligned_f32; B is padded on the way in). Rows up to the piece length carry the

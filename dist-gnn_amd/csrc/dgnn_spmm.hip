@@ -518,11 +518,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // list order varies from run to run; the result does not (a run, or a piece, is one chain with one
 // writer; pieces are merged in piece order).
 constexpr int PLAN_MAX_STAGES = 16;
-constexpr int PLAN_HDR_STAGE = 80;
+constexpr int PLAN_NCLS = 256;              // length classes: bit length and the three bits below the leading one
+constexpr int PLAN_HDR_STAGE = 2 * PLAN_NCLS + 16;
 constexpr int PLAN_HDR_NPART = PLAN_MAX_STAGES * PLAN_HDR_STAGE;
 constexpr int PLAN_HDR_INTS = PLAN_HDR_NPART + 16;
 
-__device__ __forceinline__ int len_class(int len) { return len <= 0 ? 0 : 32 - __clz(len); }
+// Runs of one class differ in length by at most 12.5 % (the groups of a wave finish together); classes are
+// ordered by length.
+__device__ __forceinline__ int len_class(int len) {
+  if (len <= 0) return 0;
+  const int bits = 32 - __clz(len);                                   // 1 .. 31
+  const int frac = bits >= 4 ? (len >> (bits - 4)) & 7 : (len << (4 - bits)) & 7;
+  return bits * 8 + frac;                                             // 8 .. 255
+}
 
 // first position in [lo, hi) whose column is >= bound (columns of a row ascend)
 __device__ __forceinline__ int col_lower_bound(const int32_t* __restrict__ col, int lo, int hi, int bound) {
@@ -535,8 +543,8 @@ __device__ __forceinline__ int col_lower_bound(const int32_t* __restrict__ col, 
 
 __global__ __launch_bounds__(256) void plan_hist_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                         int32_t n, int ns, int cbw, int piece, int* __restrict__ hdr) {
-  __shared__ int local[PLAN_MAX_STAGES][32];
-  for (int t = threadIdx.x; t < ns * 32; t += 256) local[t >> 5][t & 31] = 0;
+  __shared__ int local[PLAN_MAX_STAGES][PLAN_NCLS];
+  for (int t = threadIdx.x; t < ns * PLAN_NCLS; t += 256) local[t / PLAN_NCLS][t % PLAN_NCLS] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -556,8 +564,10 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(const int32_t* __restric
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < ns * 32; t += 256)
-    if (local[t >> 5][t & 31]) atomicAdd(&hdr[(t >> 5) * PLAN_HDR_STAGE + (t & 31)], local[t >> 5][t & 31]);
+  for (int t = threadIdx.x; t < ns * PLAN_NCLS; t += 256) {
+    const int v = local[t / PLAN_NCLS][t % PLAN_NCLS];
+    if (v) atomicAdd(&hdr[(t / PLAN_NCLS) * PLAN_HDR_STAGE + t % PLAN_NCLS], v);
+  }
 }
 
 __global__ void plan_cursor_kernel(int* __restrict__ hdr, int ns) {
@@ -565,7 +575,7 @@ __global__ void plan_cursor_kernel(int* __restrict__ hdr, int ns) {
   if (st < ns) {
     int* h = hdr + st * PLAN_HDR_STAGE;
     int at = 0;
-    for (int c = 31; c >= 0; --c) { h[32 + c] = at; at += h[c]; }
+    for (int c = PLAN_NCLS - 1; c >= 0; --c) { h[PLAN_NCLS + c] = at; at += h[c]; }
   }
 }
 
@@ -576,11 +586,11 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restric
   // A tile of 256 rows ranks its uncut runs per (stage, class) in LDS and reserves their slots with one
   // global atomic per (stage, class): millions of rows hammering a few global counters one by one cost
   // more than the SpMM itself.
-  __shared__ int lcnt[PLAN_MAX_STAGES][32], lbase[PLAN_MAX_STAGES][32];
+  __shared__ int lcnt[PLAN_MAX_STAGES][PLAN_NCLS], lbase[PLAN_MAX_STAGES][PLAN_NCLS];
   __shared__ int lend[PLAN_MAX_STAGES][256];                 // end of the run of (stage, thread)
   __shared__ unsigned short lrank[PLAN_MAX_STAGES][256];
   for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < n; t0 += (int64_t)gridDim.x * 256) {
-    for (int t = threadIdx.x; t < ns * 32; t += 256) lcnt[t >> 5][t & 31] = 0;
+    for (int t = threadIdx.x; t < ns * PLAN_NCLS; t += 256) lcnt[t / PLAN_NCLS][t % PLAN_NCLS] = 0;
     __syncthreads();
     const int64_t i = t0 + threadIdx.x;
     const bool valid = i < n;
@@ -594,8 +604,10 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restric
       a = b;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ns * 32; t += 256)
-      if (lcnt[t >> 5][t & 31]) lbase[t >> 5][t & 31] = atomicAdd(&hdr[(t >> 5) * PLAN_HDR_STAGE + 32 + (t & 31)], lcnt[t >> 5][t & 31]);
+    for (int t = threadIdx.x; t < ns * PLAN_NCLS; t += 256) {
+      const int st = t / PLAN_NCLS, c = t % PLAN_NCLS;
+      if (lcnt[st][c]) lbase[st][c] = atomicAdd(&hdr[st * PLAN_HDR_STAGE + PLAN_NCLS + c], lcnt[st][c]);
+    }
     __syncthreads();
     a = k0;
     for (int st = 0; st < ns; ++st) {
@@ -608,10 +620,10 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restric
         int* const h = hdr + st * PLAN_HDR_STAGE;
         const int np = (len + piece - 1) / piece;
         const int pbase = atomicAdd(&hdr[PLAN_HDR_NPART], np);
-        cut[st * cut_stride + atomicAdd(&h[64], 1)] = make_int4((int)i, pbase, np, 0);
+        cut[st * cut_stride + atomicAdd(&h[2 * PLAN_NCLS], 1)] = make_int4((int)i, pbase, np, 0);
         for (int p = 0; p < np; ++p) {
           const int pa = a + p * piece, pb = min(pa + piece, b);
-          sseg[atomicAdd(&h[32 + len_class(pb - pa)], 1)] = make_int4((int)i, pa, pb, pbase + p);
+          sseg[atomicAdd(&h[PLAN_NCLS + len_class(pb - pa)], 1)] = make_int4((int)i, pa, pb, pbase + p);
         }
       }
       a = b;
@@ -638,16 +650,16 @@ int auto_piece_len(int64_t nnz_per_stage) {
   return p;
 }
 
-struct DevicePlanShape { int ns, piece; int64_t nseg_max, ncut_max, npartial_max, ws_ints; };
-
-DevicePlanShape device_plan_shape(int64_t n, int64_t m, int64_t nnz, int64_t ldb) {
-  DevicePlanShape d;
-  d.ns = auto_stage_count(n, m, nnz, ldb);
-  d.piece = auto_piece_len(nnz / d.ns);
+// Sizes of a device-built plan (upper bounds; see dgnn_plan_layout in the header).
+dgnn_plan_layout device_plan_layout(int64_t n, int64_t m, int64_t nnz, int64_t ldb, int ns, int piece) {
+  dgnn_plan_layout d;
+  d.nstage = ns > 0 ? (ns > PLAN_MAX_STAGES ? PLAN_MAX_STAGES : ns) : auto_stage_count(n, m, nnz, ldb);
+  d.piece = piece > 0 ? piece : auto_piece_len(nnz / d.nstage);
+  d.hdr_ints = PLAN_HDR_INTS;
   d.ncut_max = nnz / d.piece + 1;                            // per stage
   d.nseg_max = n + nnz / d.piece + 1;                        // per stage
-  d.npartial_max = 2 * (nnz / d.piece) + 2 * d.ns + 2;
-  d.ws_ints = PLAN_HDR_INTS + 4 * d.ns * (d.nseg_max + d.ncut_max);
+  d.npartial_max = 2 * (nnz / d.piece) + 2 * d.nstage + 2;
+  d.ws_ints = PLAN_HDR_INTS + 4 * d.nstage * (d.nseg_max + d.ncut_max);
   return d;
 }
 
@@ -856,9 +868,42 @@ int dgnn_spmm_coo_f32(const int32_t* row, const int32_t* col, const float* val,
   return dgnn_spmm_csr_f32(rowptr_ws, col, val, n, m, nnz, B, ldb, C, ldc, F, alpha, beta, stream);
 }
 
+int dgnn_plan_layout_for(int32_t n, int32_t m, int64_t nnz, int64_t ldb, int32_t nstage, int32_t piece,
+                         dgnn_plan_layout* out) {
+  if (n < 0 || m < 0 || nnz < 0 || !out) return fail(DGNN_E_BADARG, "plan_layout_for: bad argument%s", "");
+  *out = device_plan_layout(n, m, nnz, ldb, nstage, piece);
+  if (out->nseg_max > 0x7fffffffLL) return fail(DGNN_E_BADARG, "plan_layout_for: block too large%s", "");
+  return DGNN_OK;
+}
+
+int dgnn_plan_build(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t m,
+                    const dgnn_plan_layout* layout, int32_t* ws, void* stream) {
+  if (!layout || layout->nstage < 1 || layout->nstage > PLAN_MAX_STAGES || layout->piece < 1 || layout->hdr_ints != PLAN_HDR_INTS)
+    return fail(DGNN_E_BADARG, "plan_build: layout does not come from dgnn_plan_layout_for%s", "");
+  if (n < 0 || m < 0) return fail(DGNN_E_BADARG, "plan_build: negative size%s", "");
+  if (!ws || !aligned(ws, 16)) return fail(DGNN_E_BADARG, "plan_build: ws must be 16-byte aligned%s", "");
+  hipStream_t s = (hipStream_t)stream;
+  const int ns = layout->nstage;
+  int* hdr = ws;
+  int4* seg = reinterpret_cast<int4*>(ws + PLAN_HDR_INTS);
+  int4* cut = seg + ns * layout->nseg_max;
+  DGNN_HIP(hipMemsetAsync(hdr, 0, PLAN_HDR_INTS * sizeof(int), s));
+  DGNN_HIP(hipMemsetAsync(seg, 0xff, (size_t)(ns * layout->nseg_max) * sizeof(int4), s));   // row = -1: unused slot
+  DGNN_HIP(hipMemsetAsync(cut, 0, (size_t)(ns * layout->ncut_max) * sizeof(int4), s));      // count = 0: unused slot
+  if (n == 0) return DGNN_OK;
+  if (!rowptr) return fail(DGNN_E_BADARG, "plan_build: null pointer%s", "");   // col may be null for an empty block
+  const int cbw = (int)(((int64_t)m + ns - 1) / ns) > 0 ? (int)(((int64_t)m + ns - 1) / ns) : 1;
+  hipLaunchKernelGGL(plan_hist_kernel, dim3(capped_blocks(n, 1024)), dim3(256), 0, s, rowptr, col, n, ns, cbw, layout->piece, hdr);
+  hipLaunchKernelGGL(plan_cursor_kernel, dim3(1), dim3(64), 0, s, hdr, ns);
+  hipLaunchKernelGGL(plan_fill_kernel, dim3(capped_blocks(n, 4096)), dim3(256), 0, s, rowptr, col, n, ns, cbw, layout->piece,
+                     hdr, seg, layout->nseg_max, cut, layout->ncut_max);
+  DGNN_HIP(hipGetLastError());
+  return DGNN_OK;
+}
+
 int dgnn_coo_aligned_workspace(int32_t n, int32_t m, int64_t nnz, int64_t ldb, int64_t* plan_ws_ints, int64_t* partial_rows) {
   if (n < 0 || m < 0 || nnz < 0 || !plan_ws_ints || !partial_rows) return fail(DGNN_E_BADARG, "coo_aligned_workspace: bad argument%s", "");
-  const DevicePlanShape d = device_plan_shape(n, m, nnz, ldb);
+  const dgnn_plan_layout d = device_plan_layout(n, m, nnz, ldb, 0, 0);
   *plan_ws_ints = d.ws_ints;
   *partial_rows = d.npartial_max;
   return DGNN_OK;
@@ -870,29 +915,18 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
                               float* partial, int64_t ldp, int32_t F,
                               float alpha, float beta, void* stream) {
   if (n == 0 || F == 0) return DGNN_OK;
-  if (!plan_ws || !aligned(plan_ws, 16)) return fail(DGNN_E_BADARG, "spmm_coo_aligned: plan_ws must be 16-byte aligned%s", "");
-  const DevicePlanShape d = device_plan_shape(n, m, nnz, ldb);
-  if (d.nseg_max > 0x7fffffffLL) return fail(DGNN_E_BADARG, "spmm_coo_aligned: block too large%s", "");
-  int rc = dgnn_coo2csr_i32(row, nnz, n, rowptr_ws, stream);
+  dgnn_plan_layout d;
+  int rc = dgnn_plan_layout_for(n, m, nnz, ldb, 0, 0, &d);
   if (rc != DGNN_OK) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  int* hdr = plan_ws;
-  int4* seg = reinterpret_cast<int4*>(plan_ws + PLAN_HDR_INTS);
-  int4* cut = seg + d.ns * d.nseg_max;
-  const int cbw = (int)((m + d.ns - 1) / d.ns);
-  DGNN_HIP(hipMemsetAsync(hdr, 0, PLAN_HDR_INTS * sizeof(int), s));
-  DGNN_HIP(hipMemsetAsync(seg, 0xff, (size_t)(d.ns * d.nseg_max) * sizeof(int4), s));   // row = -1: unused slot
-  DGNN_HIP(hipMemsetAsync(cut, 0, (size_t)(d.ns * d.ncut_max) * sizeof(int4), s));      // count = 0: unused slot
-  hipLaunchKernelGGL(plan_hist_kernel, dim3(capped_blocks(n, 1024)), dim3(256), 0, s, rowptr_ws, col, n, d.ns, cbw, d.piece, hdr);
-  hipLaunchKernelGGL(plan_cursor_kernel, dim3(1), dim3(64), 0, s, hdr, d.ns);
-  hipLaunchKernelGGL(plan_fill_kernel, dim3(capped_blocks(n, 4096)), dim3(256), 0, s, rowptr_ws, col, n, d.ns, cbw, d.piece,
-                     hdr, seg, d.nseg_max, cut, d.ncut_max);
-  DGNN_HIP(hipGetLastError());
+  rc = dgnn_coo2csr_i32(row, nnz, n, rowptr_ws, stream);
+  if (rc != DGNN_OK) return rc;
+  rc = dgnn_plan_build(rowptr_ws, col, n, m, &d, plan_ws, stream);
+  if (rc != DGNN_OK) return rc;
   int64_t seg_off[PLAN_MAX_STAGES + 1], cut_off[PLAN_MAX_STAGES + 1];
-  for (int st = 0; st <= d.ns; ++st) { seg_off[st] = st * d.nseg_max; cut_off[st] = st * d.ncut_max; }
+  for (int st = 0; st <= d.nstage; ++st) { seg_off[st] = st * d.nseg_max; cut_off[st] = st * d.ncut_max; }
   dgnn_plan plan;
-  plan.nstage = d.ns; plan.seg = reinterpret_cast<const int32_t*>(seg); plan.stage_seg_off = seg_off;
-  plan.cut = reinterpret_cast<const int32_t*>(cut); plan.stage_cut_off = cut_off;
+  plan.nstage = d.nstage; plan.seg = plan_ws + d.hdr_ints; plan.stage_seg_off = seg_off;
+  plan.cut = plan_ws + d.hdr_ints + 4 * d.nstage * d.nseg_max; plan.stage_cut_off = cut_off;
   plan.npartial = d.npartial_max; plan.max_seg_len = d.piece;
   return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
 }

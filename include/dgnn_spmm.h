@@ -129,6 +129,30 @@ typedef struct dgnn_plan {
 } dgnn_plan;
 
 /*
+ * A dgnn_plan built on the device, on the stream, from the CSR arrays alone (no host pass over the
+ * nonzeros, no host synchronisation): column-block stages by binary search in each row's ascending
+ * columns, runs grouped by length class (longest class first), long runs cut into pieces. The host never
+ * learns the counts, so the lists are sized by upper bounds and unused slots are dead (segment row = -1,
+ * cut count = 0; the kernels skip them). Workspace `ws` (int32, 16-byte aligned, ws_ints long):
+ *   [0, hdr_ints)                                   counters
+ *   then nstage lists of nseg_max segments (4 ints each), stage s at s * nseg_max
+ *   then nstage lists of ncut_max cut runs  (4 ints each), stage s at s * ncut_max
+ * so a dgnn_plan over it has seg = ws + hdr_ints, stage_seg_off[s] = s * nseg_max,
+ * cut = ws + hdr_ints + 4 * nstage * nseg_max, stage_cut_off[s] = s * ncut_max, npartial = npartial_max,
+ * max_seg_len = piece. nstage / piece = 0 ask for the library's rules.
+ * The list order depends on the run (atomic slot reservation); results computed with it do not.
+ * No counterpart in the reference.
+ */
+typedef struct dgnn_plan_layout {
+  int32_t nstage, piece;
+  int64_t hdr_ints, nseg_max, ncut_max, npartial_max, ws_ints;
+} dgnn_plan_layout;
+int dgnn_plan_layout_for(int32_t n, int32_t m, int64_t nnz, int64_t ldb, int32_t nstage, int32_t piece,
+                         dgnn_plan_layout* out);
+int dgnn_plan_build(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t m,
+                    const dgnn_plan_layout* layout, int32_t* ws, void* stream);
+
+/*
  * C[n x F] = alpha * A * B + beta * C with a work plan: the fast path.
  *   col/val        the CSR arrays the plan indexes
  *   B              ldb >= F, ldb % 4 == 0, 16-byte aligned (see dgnn_pad_rows_f32); columns

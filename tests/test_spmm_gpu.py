@@ -369,3 +369,48 @@ def test_reference_signature_takes_the_fast_kernel_without_a_plan(n, m, nnz, F, 
     again = torch.from_numpy(C0).to(dev)
     spmm_cpp.spmm_cusparse(*args, again, alpha, beta)
     assert torch.equal(again, Cg)                             # list order varies between runs, the result does not
+
+
+@pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece,alpha,beta', [
+    (1000, 900, 60000, 2, 602, 3, 256, 1.0, 1.0), (3000, 3000, 90000, 3, 256, 4, 64, 1.0, 1.0),
+    (2000, 6000, 120000, 3, 41, 2, 1024, 0.5, 2.0), (900, 7000, 80000, 2, 1433, 16, 700, 1.0, 0.0),
+    (1500, 5000, 100000, 2, 100, 1, 1000000, 1.0, 1.0), (64, 4096, 3000, 0, 47, 5, 8, 1.0, 1.0),
+    (300, 300, 0, 0, 16, 2, 128, 1.0, 1.0)])
+def test_device_built_plan_matches_oracle(n, m, nnz, hubs, F, nstage, piece, alpha, beta):
+    """dgnn_plan_build: the plan made on the device (stages by binary search, length classes, cut runs, dead
+    slots) drives the same kernels to the same answer: oracle bits on every row no stage cuts, the fp64
+    bound on the rest, identical from run to run although the list order is not."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(n + 7 * F + nstage)
+    if nnz:
+        row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
+    else:
+        row, col, val = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if beta == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), alpha, beta)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    plan = spmm_cpp.DevicePlan(blk, nstage, piece, F)
+    assert plan.nstage == nstage and plan.piece_len == piece
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+    Cg = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, Cg, alpha, beta, plan)
+    got = Cg.cpu().numpy()
+    rowptr = ref_cpu.coo2csr(row, n)
+    _check(got, want, rowptr, col, val, B, np.nan_to_num(C0), alpha, beta)
+    # rows with a run longer than the piece length inside one column block are the only ones allowed to differ
+    cbw = -(-m // nstage)
+    runs = np.zeros((n, nstage), dtype=np.int64)
+    np.add.at(runs, (row, col // cbw), 1)
+    uncut = runs.max(axis=1) <= piece
+    assert np.array_equal(got[uncut], want[uncut])
+    nseg, ncut, npart = plan.counts()
+    assert nseg == int((runs > 0).sum() + (np.ceil(runs / piece)[runs > piece] - 1).sum())
+    assert ncut == int((runs > piece).sum()) and npart == int(np.ceil(runs / piece)[runs > piece].sum())
+    again = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, again, alpha, beta, spmm_cpp.DevicePlan(blk, nstage, piece, F))
+    assert torch.equal(again, Cg)

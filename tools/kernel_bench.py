@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--torch-ref', action='store_true')
     ap.add_argument('--plan-variants', default='0')
     ap.add_argument('--drop-in-variant', type=int, default=0)
+    ap.add_argument('--builder', default='torch', choices=['torch', 'device'], help='who builds the work plans')
     ap.add_argument('--drop-in', action='store_true', help='also time the reference-signature call spmm_cusparse(row, col, val, ...)')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
     args = ap.parse_args()
@@ -114,8 +115,14 @@ def main():
             else:
                 ns, pl_len = (int(x) for x in spec.split(':')[:2])
             nhot = 0
+            if args.builder == 'device':
+                nhot = F                                  # device plans size their lists for a width
             if (ns, pl_len, nhot) not in plans:
-                plans[(ns, pl_len, nhot)] = spmm_cpp.SegPlan(A, ns, pl_len)
+                t0 = time.perf_counter()
+                plans[(ns, pl_len, nhot)] = (spmm_cpp.DevicePlan(A, ns, pl_len, F) if args.builder == 'device'
+                                             else spmm_cpp.SegPlan(A, ns, pl_len))
+                torch.cuda.synchronize()
+                print(f'# {args.builder} plan built in {1e3 * (time.perf_counter() - t0):.1f} ms', flush=True)
                 pp = plans[(ns, pl_len, nhot)]
                 print(f'# plan nstage={ns} piece={pl_len} nhot={nhot}: nseg={pp.nseg} ncut={pp.ncut} npartial={pp.npartial}', flush=True)
             pl = plans[(ns, pl_len, nhot)]

@@ -414,3 +414,52 @@ def test_device_built_plan_matches_oracle(n, m, nnz, hubs, F, nstage, piece, alp
     again = torch.from_numpy(C0).to(dev)
     spmm_cpp.spmm_plan(blk, Bp, again, alpha, beta, spmm_cpp.DevicePlan(blk, nstage, piece, F))
     assert torch.equal(again, Cg)
+
+
+def test_full_size_reddit_shape_properties():
+    """BASELINE config 1 at full size (232,965 nodes, 114.8 M nonzeros) through properties that need no
+    CPU oracle: exact linearity under a power-of-two scale, identical columns for identical inputs, row sums
+    against an fp64 reduction, planned == plan-less == row kernel on every row no plan cuts, run-to-run bits."""
+    import spmm_cpp
+    from coo_graph import synthetic, graph_utils
+    dev = torch.device('cuda:0')
+    n, e, *_ = synthetic.SHAPES['reddit']
+    d = synthetic.make_dataset('reddit', seed=0, device=dev, with_features=False)
+    adj = graph_utils.sym_normalization(d['edge_index'], n)
+    del d
+    A = spmm_cpp.CsrBlock.from_coo(adj)
+    assert A.n == n and A.nnz == adj._nnz() > 114_000_000
+    F = 64
+    g = torch.Generator(device=dev).manual_seed(3)
+    B = torch.rand(n, F, device=dev, generator=g)
+    Z = torch.zeros(n, F, device=dev)
+    spmm_cpp.aggregate(A, B, Z)                                   # resident plan (host-built), padded in place
+    Z2 = torch.zeros(n, F, device=dev)
+    spmm_cpp.aggregate(A, B * 2.0, Z2)
+    assert torch.equal(Z2, Z * 2.0)                               # scaling by 2 commutes with every rounding
+    Zr = torch.zeros(n, F, device=dev)
+    spmm_cpp.aggregate(A, B, Zr)
+    assert torch.equal(Zr, Z)                                     # no atomics: same bits every run
+    # ones in, row sums out: every column the same bits, and the fp64 row sums within 1e-5
+    ones = torch.ones(n, F, device=dev)
+    S = torch.zeros(n, F, device=dev)
+    spmm_cpp.aggregate(A, ones, S)
+    assert torch.equal(S, S[:, :1].expand(-1, F))
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (A.rowptr[1:] - A.rowptr[:-1]).long())
+    want = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows, A.val.double())
+    assert ((S[:, 0].double() - want).abs() <= 1e-5 * want.abs()).all()
+    del rows, ones, S
+    # the three kernels paths agree bit for bit wherever no path cuts the row (runs <= 128 in every plan)
+    ci = adj.indices()
+    Zc = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_cusparse(ci[0].int(), ci[1].int(), adj.values(), n, n, B, Zc, 1.0, 1.0)     # plan-less, device-built plan
+    Zk = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_csr(A, B, Zk, 1.0, 1.0)                                                     # row kernel, strict chain
+    short = (A.rowptr[1:] - A.rowptr[:-1]) <= 128
+    assert int(short.sum()) > 50_000
+    assert torch.equal(Z[short], Zk[short]) and torch.equal(Zc[short], Zk[short])
+    # cut hub rows (up to 108 K nonzeros): fixed-order piece sums, judged against an fp64 product -- all terms
+    # are positive here, so the bound 1e-5 * sum|a*b| is 1e-5 relative, element by element
+    exact = torch.sparse.mm(torch.sparse_coo_tensor(ci, adj.values().double(), (n, n)), B.double())
+    for got in (Z, Zc):
+        assert ((got.double() - exact).abs() <= 1e-5 * exact).all()

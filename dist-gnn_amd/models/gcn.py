@@ -164,6 +164,8 @@ class StagePipeline:
                       then ONE SpMM of the rank's whole row slab against the gathered matrix when the
                       block list carries the slab (Parted_COO_Graph sets it; DGNN_FUSED_SLAB=0 or a
                       plain list fall back to the P per-block SpMMs).
+    mode 'agpipe'     the all-gather cut into two column slabs: slab 2 travels while slab 1 is multiplied
+                      (collective bandwidth and overlap; needs at least 64 feature columns).
     mode 'needed'     point-to-point: the owner of stage j sends every peer only the rows of H_j
                       that peer's block references (NeededRows), pipelined like 'bcast'.
     mode 'auto'       (default) the first time a (tag, shape) is aggregated, the forms are run
@@ -189,8 +191,8 @@ class StagePipeline:
 
     def __init__(self, mode=None, inflight=None, cache_input=None):
         self.mode = mode or os.environ.get('DGNN_PIPELINE', 'auto')
-        if self.mode not in ('auto', 'bcast', 'allgather', 'needed'):
-            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather or needed')
+        if self.mode not in ('auto', 'bcast', 'allgather', 'agpipe', 'needed'):
+            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather, agpipe or needed')
         self.inflight = max(1, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))   # 1 = no overlap (debugging)
         self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
         self._bufs = {}
@@ -267,6 +269,54 @@ class StagePipeline:
                 keep[src] = block
             with timer.timing_cuda('spmm'):
                 spmm(adj_parts[blk], block, z)
+        return z
+
+    def _run_agpipe(self, adj_parts, feat, stages, group, z, chunks=2):
+        """All-gather in column chunks: the feature columns are cut into `chunks` slabs (at multiples of 32
+        floats) and the all-gather of slab c + 1 travels while slab c is multiplied -- the collective keeps
+        every xGMI link busy AND overlaps the SpMM. Columns are independent, so the bits do not change."""
+        env = DistEnv.env
+        rank, timer = env.rank, env.timer
+        P, s, F = len(stages), feat.size(0), feat.size(1)
+        step = (-(-F // chunks) + 31) // 32 * 32                  # columns per slab: ceil(F / chunks), on a 32-float grid
+        bounds = [(c0, min(c0 + step, F)) for c0 in range(0, F, step)]
+        if len(bounds) < 2:
+            return self._run_allgather(adj_parts, feat, stages, group, z, None)
+        on_gpu = feat.is_cuda and _spmm_override is None
+        slab = getattr(adj_parts, 'slab', None) if self.fused_slab else None
+        fused = slab is not None and slab.size(1) == P * s and [src for src, _ in stages] == list(range(P))
+        members = sorted(src for src, _ in stages)
+        pending = {}
+
+        def post(c):
+            c0, c1 = bounds[c]
+            w = c1 - c0
+            ld = (w + 31) // 32 * 32 if on_gpu else w
+            if on_gpu and (ld != w or c0 % 4):
+                import spmm_cpp
+                own = spmm_cpp.pad_rows(feat[:, c0:c1], self._buffers((s, ld), feat, 1, f'agp-own{c}')[0])
+            else:
+                own = self._buffers((s, ld), feat, 1, f'agp-own{c}')[0]
+                own.copy_(feat[:, c0:c1])
+            gathered = self._buffers((P * s, ld), feat, 1, f'agp-gather{c}')[0]
+            pending[c] = (dist.all_gather_into_tensor(gathered, own, group=group, async_op=True), gathered, w)
+
+        post(0)
+        for c, (c0, c1) in enumerate(bounds):
+            if c + 1 < len(bounds):
+                post(c + 1)
+            work, gathered, w = pending.pop(c)
+            with timer.timing_cuda('broadcast'):
+                work.wait()
+            zc = z[:, c0:c1]
+            with timer.timing_cuda('spmm'):
+                if fused:
+                    spmm(slab, gathered[:, :w], zc)
+                else:
+                    for src, blk in stages:
+                        pos = members.index(src)
+                        spmm(adj_parts[blk], gathered[pos * s:(pos + 1) * s, :w], zc)
+        self.transfers += P
         return z
 
     def _run_bcast(self, adj_parts, feat, stages, group, z, keep, policy):
@@ -391,7 +441,7 @@ class StagePipeline:
         import time
         sent = self.transfers
 
-        forms = ['bcast', 'allgather']
+        forms = ['bcast', 'allgather'] + (['agpipe'] if feat.size(1) > 32 else [])
         if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.75:
             forms.append('needed')
         moved = (self.rows_moved, self.rows_full)
@@ -405,6 +455,8 @@ class StagePipeline:
                 self._run_bcast(adj_parts, feat, stages, group, z, None, None)
             elif form == 'allgather':
                 self._run_allgather(adj_parts, feat, stages, group, z, None)
+            elif form == 'agpipe':
+                self._run_agpipe(adj_parts, feat, stages, group, z)
             else:
                 self._run_needed(adj_parts, feat, stages, group, z)
             if feat.is_cuda:
@@ -490,6 +542,9 @@ class StagePipeline:
         if form == 'needed' and plain and self._needed_ok(adj_parts, stages, group):
             self._run_needed(adj_parts, feat, stages, group, z)
             keep = None                                     # compact blocks are not kept: nothing to reuse
+        elif form == 'agpipe' and can_gather:
+            self._run_agpipe(adj_parts, feat, stages, group, z)
+            keep = None
         elif form == 'allgather' and can_gather:
             self._run_allgather(adj_parts, feat, stages, group, z, keep)
         else:

@@ -23,7 +23,12 @@ def _oracle_spmm(A, B, C):
     from oracle import ref_cpu
     idx = A.indices().numpy()
     Bc = np.ascontiguousarray(B.detach().numpy(), dtype=np.float32)
-    ref_cpu.spmm_coo(idx[0], idx[1], A.values().numpy(), A.size(0), A.size(1), Bc, C.numpy(), 1.0, 1.0)
+    if C.is_contiguous():
+        ref_cpu.spmm_coo(idx[0], idx[1], A.values().numpy(), A.size(0), A.size(1), Bc, C.numpy(), 1.0, 1.0)
+    else:                                                # a column slab of z (pipelined all-gather form)
+        tmp = C.contiguous()
+        ref_cpu.spmm_coo(idx[0], idx[1], A.values().numpy(), A.size(0), A.size(1), Bc, tmp.numpy(), 1.0, 1.0)
+        C.copy_(tmp)
 
 
 def _cpu_gather(src, idx, dst):
@@ -112,6 +117,7 @@ def _run(world, name, mode='bcast', inflight=2, tmp='/tmp'):
     (2, 'tiny', 'bcast', 2), (3, 'tiny', 'bcast', 2), (3, 'ragged', 'bcast', 3), (2, 'ragged', 'allgather', 2),
     (2, 'directed', 'bcast', 2), (2, 'multilabel', 'bcast', 2), (1, 'tiny', 'bcast', 2),
     (2, 'tiny', 'auto', 2), (3, 'ragged', 'auto', 2), (2, 'tiny', 'needed', 2), (3, 'ragged', 'needed', 3),
+    (2, 'tiny', 'agpipe', 2), (3, 'ragged', 'agpipe', 2),
     (2, 'directed', 'needed', 2)])
 def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
     out = _run(world, name, mode, inflight, str(tmp_path))
@@ -124,7 +130,7 @@ def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
             assert 0 < res['rows'][0] <= res['rows'][1], res['rows']
         if mode == 'auto':       # every rank settled on the same form for every (tag, shape) it tuned
             assert res['choices'] and res['choices'] == out[0]['choices'], (res['choices'], out[0]['choices'])
-            assert set(res['choices'].values()) <= {'bcast', 'allgather'} and res['pipeline'].startswith('auto(')
+            assert set(res['choices'].values()) <= {'bcast', 'allgather', 'agpipe', 'needed'} and res['pipeline'].startswith('auto(')
     if out[0].get('gold_losses'):
         got, want = np.array(out[0]['losses']), np.array(out[0]['gold_losses'])
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=6e-5)      # reference logs 4 decimals
@@ -210,7 +216,7 @@ def _eight_worker(rank, world, port, log_dir, q):
         full = coo_graph.COO_Graph('odd', attr_dict=_odd_graph())
         g = coo_graph.Parted_COO_Graph('odd', rank, world, attr_dict=full.partition(world, save=False)[rank])
         res = {'rows': g.local_num_nodes}
-        for mode in ('bcast', 'allgather', 'needed', 'auto'):
+        for mode in ('bcast', 'allgather', 'agpipe', 'needed', 'auto'):
             gcn._pipeline = gcn.StagePipeline(mode=mode, inflight=3, cache_input=False)
             res[mode] = gcn.broadcast(g.adj_parts, g.features, 'ForwardL1').numpy()
         gcn._pipeline = gcn.StagePipeline(mode='auto')
@@ -227,7 +233,7 @@ def _eight_worker(rank, world, port, log_dir, q):
 def _odd_graph():
     g0 = torch.Generator().manual_seed(21)
     n, e = 203, 1500                                    # 203 = 8 * 26 - 5: the last block is padded
-    return {"edge_index": torch.randint(0, n, (2, e), generator=g0), "features": torch.rand(n, 9, generator=g0),
+    return {"edge_index": torch.randint(0, n, (2, e), generator=g0), "features": torch.rand(n, 70, generator=g0),
             "labels": torch.randint(0, 4, (n,), generator=g0), "train_mask": torch.rand(n, generator=g0) < 0.6,
             "val_mask": torch.zeros(n, dtype=torch.bool), "test_mask": torch.zeros(n, dtype=torch.bool),
             "num_nodes": n, "num_edges": e, "num_classes": 4}
@@ -244,7 +250,7 @@ def test_eight_ranks_every_form_equals_the_unpartitioned_product(tmp_path):
     full = coo_graph.COO_Graph('odd', attr_dict=_odd_graph())
     adj = full.adj.coalesce()
     n = full.num_nodes
-    want = np.zeros((n, 9), dtype=np.float32)
+    want = np.zeros((n, 70), dtype=np.float32)
     ref_cpu.spmm_coo(adj.indices()[0].numpy(), adj.indices()[1].numpy(), adj.values().numpy(), n, n,
                      np.ascontiguousarray(full.features.numpy()), want, 1.0, 1.0)
     world = 8
@@ -261,7 +267,7 @@ def test_eight_ranks_every_form_equals_the_unpartitioned_product(tmp_path):
         assert 'error' not in res, res.get('error')
     s = out[0]['rows']
     assert s == 26
-    for mode in ('bcast', 'allgather', 'needed', 'auto'):
+    for mode in ('bcast', 'allgather', 'agpipe', 'needed', 'auto'):
         z = np.concatenate([out[r][mode] for r in range(world)])
         assert z.shape[0] == s * world and np.array_equal(z[:n], want), mode
         assert not z[n:].any()                                   # padding rows aggregate nothing

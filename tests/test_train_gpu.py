@@ -122,9 +122,12 @@ def test_transfer_forms_over_rccl_world1(env, F):
     parts.slab = A                                      # one rank: the row slab is the block itself
     kept = {}
     z4 = pipe._run_allgather(parts, H, stages, env.world_group, torch.zeros(n, F, device=dev), kept)
+    z5 = pipe._run_agpipe(parts, H, stages, env.world_group, torch.zeros(n, F, device=dev))          # column slabs, fused
+    z6 = pipe._run_agpipe([A], H, stages, env.world_group, torch.zeros(n, F, device=dev), chunks=3)  # per block
     torch.cuda.synchronize()
     assert torch.equal(z1, want) and torch.equal(z2, want) and torch.equal(z3, want) and torch.equal(z4, want)
-    assert 'gathered' in kept and pipe.transfers == 4
+    assert torch.equal(z5, want) and torch.equal(z6, want)
+    assert 'gathered' in kept and pipe.transfers == 6
 
 
 @pytest.mark.parametrize('F', [602, 100, 41])

@@ -11,9 +11,9 @@
 //   spmm_rows_kernel   general operands (any alignment / leading dimension). One group of L
 //                      lanes owns one output row; strictly ascending accumulation.
 //   spmm_stage_kernel  the fast path: needs a work plan (dgnn_plan) and a B whose rows are
-//                      16-byte aligned (ldb % 4 == 0). Feature chunks of 64 (or 32) floats,
-//                      XCD-aware chunk-major work order, column-block stages, long rows cut
-//                      in pieces.
+//                      16-byte aligned (ldb % 4 == 0). Feature chunks of 64 or 128 floats,
+//                      XCD-aware chunk-major work order with balanced XCD shares, column-block
+//                      stages, long rows cut in pieces, 16- or 32-lane groups.
 //
 // In both, a (col, val) run of a row is read with coalesced loads, one entry per lane. The row
 // kernel hands entries lane-to-lane (v_readlane when L == 64, ds_bpermute otherwise); the
@@ -24,6 +24,10 @@
 // the same chain as ATen's CPU sparse addmm (oracle/spmm_ref.c), so results are bit-identical
 // to the oracle except for rows the plan cuts into pieces (fixed-order piece sums:
 // deterministic, within fp32 rounding of the chain). No atomics anywhere.
+//
+// A work plan comes either from the host (spmm_cpp.SegPlan: exact longest-first order) or from the
+// plan_*_kernel trio below, which builds the same structure on the device without the host ever
+// learning a count (dgnn_plan_build; used by the plan-less reference call dgnn_spmm_coo_aligned_f32).
 //
 // 64-wide wavefronts are assumed throughout (gfx950 only).
 

@@ -96,7 +96,7 @@ class AdaptiveGCNLayer(torch.autograd.Function):
         ag = adaptive_broadcast(ctx.adj_parts, grad_output, 'backward_' + ctx.btype)
         with DistEnv.env.timer.timing_cuda('mm'):
             grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
-            grad_weight = torch.mm(features.t(), ag)
+            grad_weight = _gcn.grad_weight_product(features, ag)
         with DistEnv.env.timer.timing_cuda('all_reduce'):
             DistEnv.env.all_reduce_sum(grad_weight)
         return grad_features, grad_weight, None, None

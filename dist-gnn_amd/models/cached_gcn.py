@@ -79,7 +79,7 @@ class CachedDistGCNLayer(torch.autograd.Function):
         ag = cached_broadcast(ctx.adj_parts, grad_output, 'Backward' + ctx.tag)
         with DistEnv.env.timer.timing_cuda('mm'):
             grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
-            grad_weight = torch.mm(features.t(), ag)
+            grad_weight = _gcn.grad_weight_product(features, ag)
         with DistEnv.env.timer.timing_cuda('all_reduce'):
             DistEnv.env.all_reduce_sum(grad_weight)
         return grad_features, grad_weight, None, None

@@ -85,7 +85,7 @@ class Dist15DLayer(torch.autograd.Function):
         ag = broadcast_15d(ctx.adj_parts, grad_output, 'Backward' + ctx.tag)
         with DistEnv.env.timer.timing_cuda('mm'):
             grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
-            grad_weight = torch.mm(features.t(), ag)
+            grad_weight = _gcn.grad_weight_product(features, ag)
         with DistEnv.env.timer.timing_cuda('all_reduce'):
             dist.all_reduce(grad_weight, op=dist.ReduceOp.SUM, group=_rep.col_group)
         return grad_features, grad_weight, None, None

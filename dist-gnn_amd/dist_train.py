@@ -56,9 +56,16 @@ def train_step(model, optimizer, loss_func, g, env):
     """One epoch of dist_train.py:37-45: forward, loss on the local training nodes, backward, step."""
     outputs = model(g.features)
     optimizer.zero_grad()
-    local_y = g.local_labels[g.local_train_mask]
+    # outputs[mask] / labels[mask] of dist_train.py:41-42, with the mask turned into row indices once: boolean
+    # indexing runs nonzero() and waits for its size on the host every epoch, which stops the host from
+    # queueing the next stages ahead of the GPU. Same rows, same order, same loss.
+    cached = getattr(g, '_train_rows', None)
+    if cached is None or cached[0] is not g.local_train_mask:
+        idx = torch.nonzero(g.local_train_mask).flatten()
+        cached = g._train_rows = (g.local_train_mask, idx, g.local_labels[idx])
+    _, idx, local_y = cached
     if local_y.size(0) > 0:
-        loss = loss_func(outputs[g.local_train_mask], local_y)
+        loss = loss_func(outputs.index_select(0, idx), local_y)
     else:
         env.logger.log('Warning: no training nodes in this partition! Backward fake loss.')
         loss = (outputs * 0).sum()

@@ -983,9 +983,14 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
         const int64_t stage_bytes = (int64_t)(m / plan->nstage + 1) * ldb * 4;
         // A plan that leaves very long runs whole (the plan-less reference call) is bound by the serial walk
         // of its longest run: there, 8 in flight.
-        const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100
-                      : plan->max_seg_len > 16384 ? 8 : (stage_bytes <= (256ll << 20) ? 4 : 2);
         const bool wide_group = g_variant == 32 || (g_variant != 16 && ldb >= 256);   // 512-B slices from 256 floats up
+        // ... and 8 again when the launch is small (under ~200 K lane groups: the blocks of a 4- or 8-rank
+        // partition, or one-chunk-wide features): few waves per CU, so each must keep more in flight and
+        // the longest pieces set the time (measured -2..-25 %).
+        const int64_t lane_groups = (int64_t)ns * ((ldb / 4 + (wide_group ? 32 : 16) - 1) / (wide_group ? 32 : 16));
+        const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100
+                      : (plan->max_seg_len > 16384 || lane_groups < 200000) ? 8
+                      : (stage_bytes <= (256ll << 20) ? 4 : 2);
 #define DGNN_LAUNCH(LL, UU) launch_stage<LL, UU>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s)
         if (wide_group) rc = (u == 2) ? DGNN_LAUNCH(32, 2) : (u == 4) ? DGNN_LAUNCH(32, 4) : (u == 6) ? DGNN_LAUNCH(32, 6) : DGNN_LAUNCH(32, 8);
         else rc = (u == 2) ? DGNN_LAUNCH(16, 2) : (u == 4) ? DGNN_LAUNCH(16, 4) : (u == 6) ? DGNN_LAUNCH(16, 6) : DGNN_LAUNCH(16, 8);

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Compute side of the exchange forms on ONE rank's share of an N-rank partition (GPU only): P per-block
+SpMMs (bcast / needed forms) against one SpMM over the rank's row slab (all-gather forms).
+   python tools/slab_bench.py --shape reddit --parts 8 --F 602,256,41"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'dist-gnn_amd'))
+import spmm_cpp  # noqa: E402
+from coo_graph import synthetic, graph_utils, parted_coo_graph  # noqa: E402
+
+
+def timed(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--shape', default='reddit')
+    ap.add_argument('--parts', type=int, default=8)
+    ap.add_argument('--rank', type=int, default=0)
+    ap.add_argument('--F', default='602,256,41')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    n = synthetic.SHAPES[args.shape][0]
+    d = synthetic.make_dataset(args.shape, seed=0, device=dev, with_features=False)
+    adj = graph_utils.sym_normalization(d['edge_index'], n)
+    del d
+    P = args.parts
+    s = (n + P - 1) // P
+    slab = graph_utils.sparse_2d_split(adj, s)[args.rank]
+    slab = torch.sparse_coo_tensor(slab.indices(), slab.values(), (s, s * P), is_coalesced=True)
+    blocks = graph_utils.sparse_2d_split(slab, s, split_dim=1)
+    A_slab = spmm_cpp.CsrBlock.from_coo(slab)
+    A_blk = [spmm_cpp.CsrBlock.from_coo(b) for b in blocks]
+    print(f'# {args.shape} rank {args.rank} of {P}: slab {s} x {s * P}, nnz {A_slab.nnz}', flush=True)
+    for F in [int(x) for x in args.F.split(',')]:
+        H = spmm_cpp.pad_rows(torch.rand(s * P, F, device=dev))
+        z1 = torch.zeros(s, F, device=dev)
+        z2 = torch.zeros(s, F, device=dev)
+
+        def per_block():
+            for j, blk in enumerate(A_blk):
+                spmm_cpp.aggregate(blk, H[j * s:(j + 1) * s, :F], z1)
+
+        def fused():
+            spmm_cpp.aggregate(A_slab, H[:, :F], z2)
+        z1.zero_(); per_block(); z2.zero_(); fused()
+        same = torch.equal(z1, z2)
+        tb, tf = timed(per_block), timed(fused)
+        print(f'F={F:4d}  {P} block SpMMs {tb:7.3f} ms   one slab SpMM {tf:7.3f} ms   same bits: {same}', flush=True)
+
+
+if __name__ == '__main__':
+    main()

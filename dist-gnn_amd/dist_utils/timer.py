@@ -18,24 +18,27 @@ import torch
 
 
 class TimerCtx:
-    def __init__(self, timer, key, cuda):
+    def __init__(self, timer, key, cuda, stream=None):
         self.timer, self.key = timer, key
-        self.cuda = cuda and torch.cuda.is_available()
+        self.cuda = cuda and timer.cuda_ok
         self.sync = self.cuda and timer.sync
+        self.stream = stream
 
     def __enter__(self):
         if self.sync:
             torch.cuda.synchronize()
         if self.cuda and not self.sync:
+            if self.stream is None:              # looked up once per region (the lookup costs more than a record)
+                self.stream = torch.cuda.current_stream()
             self.ev0 = torch.cuda.Event(enable_timing=True)
-            self.ev0.record()
+            self.ev0.record(self.stream)
         self.t0 = time.time()
         return self
 
     def __exit__(self, exc_type, exc, tb):
         if self.cuda and not self.sync:
             ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record()
+            ev1.record(self.stream)
             pairs = self.timer.pending[self.key]
             pairs.append((self.ev0, ev1))
             if len(pairs) > 1024:                 # long runs: fold the finished pairs, without synchronising
@@ -53,6 +56,7 @@ class DistTimer:
     def __init__(self, env):
         self.env = env
         self.sync = os.environ.get('DGNN_TIMER_SYNC', '0') == '1'
+        self.cuda_ok = torch.cuda.is_available()
         self.start_time_dict = {}
         self.duration_dict = defaultdict(float)
         self.count_dict = defaultdict(int)
@@ -69,8 +73,9 @@ class DistTimer:
     def timing(self, key):
         return TimerCtx(self, key, cuda=False)
 
-    def timing_cuda(self, key):
-        return TimerCtx(self, key, cuda=True)
+    def timing_cuda(self, key, stream=None):
+        """``stream``: the stream the region runs on, if the caller already holds it (saves the lookup)."""
+        return TimerCtx(self, key, cuda=True, stream=stream)
 
     def start(self, key):
         self.start_time_dict[key] = time.time()

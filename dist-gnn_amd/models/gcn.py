@@ -322,6 +322,7 @@ class StagePipeline:
     def _run_bcast(self, adj_parts, feat, stages, group, z, keep, policy):
         env = DistEnv.env
         rank, timer = env.rank, env.timer
+        cs = torch.cuda.current_stream(feat.device) if feat.is_cuda else None
         n, F = len(stages), feat.size(1)
         ld = self._wire_width(feat)
         own = None
@@ -358,7 +359,7 @@ class StagePipeline:
                 post(i + depth - 1)
             work, block = pending.pop(i)
             _trace('bcast wait', rank, 'stage', i, 'src', src)
-            with timer.timing_cuda('broadcast'):
+            with timer.timing_cuda('broadcast', cs):
                 if work is not None:
                     work.wait()
             _trace('bcast got', rank, 'stage', i)
@@ -366,7 +367,7 @@ class StagePipeline:
                 policy.arrived(src, block)
             if keep is not None and src != rank:
                 keep[src] = block
-            with timer.timing_cuda('spmm'):
+            with timer.timing_cuda('spmm', cs):
                 spmm(adj_parts[blk], block, z)
         return z
 

@@ -460,11 +460,15 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None):
         raise RuntimeError('spmm_plan: operands are on different devices')
     if plan is None:
         plan = _plan_for(A, F)
-    with torch.cuda.device(C.device):
-        P = plan.partial(ldb, C.device)
-        rc = _lib.dgnn_spmm_plan_f32(ctypes.byref(plan.c), A.col.data_ptr(), A.val.data_ptr(), A.n, A.m,
-                                     bptr, ldb, cptr, ldc, P.data_ptr(), ldb, F, float(alpha), float(beta),
-                                     _stream(C))
+    dev = C.device
+    P = plan.partial(ldb, dev)
+    args = (ctypes.byref(plan.c), A.col.data_ptr(), A.val.data_ptr(), A.n, A.m, bptr, ldb, cptr, ldc,
+            P.data_ptr(), ldb, F, float(alpha), float(beta))
+    if torch.cuda.current_device() == dev.index:         # the usual case: no device switch to pay for
+        rc = _lib.dgnn_spmm_plan_f32(*args, _stream(C))
+    else:
+        with torch.cuda.device(dev):
+            rc = _lib.dgnn_spmm_plan_f32(*args, _stream(C))
     _check(rc, 'spmm_plan')
 
 

@@ -47,6 +47,18 @@ def build_rank_graph(args, env):
     shape = synthetic.SHAPES[args.workload]
     n = int(shape[0] * args.scale)
     e = int(shape[1] * (args.scale ** 2 if args.scale < 1 else 1))
+    if args.lean or args.workload == 'papers':
+        # every rank builds only its own part (no full normalised adjacency / feature matrix anywhere)
+        rep = args.rep if args.model == 'GCN15D' else 1
+        nblocks, block = env.world_size // rep, env.rank // rep
+        mine = synthetic.make_partition(args.workload, block, nblocks, seed=args.seed, device=dev, num_nodes=n, num_edges=e)
+        g = coo_graph.Parted_COO_Graph(args.workload, block, nblocks, device=dev, attr_dict=mine)
+        nnz_local = torch.tensor([float(g.local_num_edges)], dtype=torch.float64, device=dev)
+        if rep == 1:
+            torch.distributed.all_reduce(nnz_local)
+        else:
+            nnz_local = nnz_local * nblocks               # replicas hold the same block: estimate
+        return g, n, int(nnz_local.item())
     raw = synthetic.make_dataset(args.workload, seed=args.seed, device=dev, num_nodes=n, num_edges=e)
     raw = graph_utils.preprocess(args.workload, raw, 'GCN')
     nnz_total = raw['adj']._nnz()
@@ -114,7 +126,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='reddit', choices=['reddit', 'products', 'cora'])
+    ap.add_argument('--workload', default='reddit', choices=['reddit', 'products', 'cora', 'papers'])
+    ap.add_argument('--lean', action='store_true', help='build only this rank\'s part (always on for papers)')
     ap.add_argument('--layers', type=int, default=None)
     ap.add_argument('--hidden', type=int, default=256)
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the graph (debug only; invalidates the number)')
@@ -131,7 +144,7 @@ def main():
     ap.add_argument('--transform-first', action='store_true',
                     help='opt-in A_hat (H W) ordering for layers with F_out < F_in (re-associated fp32; not the headline)')
     args = ap.parse_args()
-    layers = args.layers or {'reddit': 2, 'products': 3, 'cora': 2}[args.workload]
+    layers = args.layers or {'reddit': 2, 'products': 3, 'cora': 2, 'papers': 4}[args.workload]
     if args.model in ('AdaptiveGCN', 'CachedGCN'):
         layers = 2                                   # fixed two-layer models in the reference
 

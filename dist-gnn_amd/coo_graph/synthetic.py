@@ -26,9 +26,11 @@ SHAPES = {
 }
 
 
-def rmat_undirected(num_nodes, num_edges, seed=0, device='cpu', abcd=(0.57, 0.19, 0.19, 0.05), batch=1 << 25):
+def rmat_undirected(num_nodes, num_edges, seed=0, device='cpu', abcd=(0.57, 0.19, 0.19, 0.05), batch=None):
     """Exactly `num_edges` distinct undirected edges {u, v}, u != v, as int64 keys u*N+v with u < v."""
     dev = torch.device(device)
+    if batch is None:                                   # candidates drawn per round (part of the stream: fixed rule)
+        batch = 1 << (25 if num_edges < (1 << 28) else 28)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     scale = max(1, math.ceil(math.log2(num_nodes)))
@@ -73,18 +75,78 @@ def make_dataset(shape='cora', seed=0, device='cpu', num_nodes=None, num_edges=N
     keys = rmat_undirected(n, e, seed=seed, device=dev)
     lo, hi = keys // n, keys % n
     edge_index = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed + 1)
     out = {"edge_index": edge_index, "num_nodes": n, "num_edges": edge_index.size(1), "num_classes": c}
     if with_features:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + 1)
         if shape == 'cora':   # binary bag-of-words, ~1.27 % dense
             feats = (torch.rand(n, f, generator=gen, device=dev) < 0.0127).to(torch.float32)
         else:
             feats = torch.randn(n, f, generator=gen, device=dev)
         out["features"] = feats
-    out["labels"] = torch.randint(0, c, (n,), generator=gen, device=dev).to(torch.int16 if c > 127 else torch.int8)
+    out.update(_labels_and_masks(n, c, tf, seed, dev))
+    return out
+
+
+def _labels_and_masks(n, c, tf, seed, dev):
+    """Labels and the train/val/test split of all n nodes from their own seeded stream (so a rank that
+    builds only its own part, make_partition, gets the very same ones)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 2)
+    labels = torch.randint(0, c, (n,), generator=gen, device=dev).to(torch.int16 if c > 127 else torch.int8)
     r = torch.rand(n, generator=gen, device=dev)
-    out["train_mask"] = r < tf
-    out["val_mask"] = (r >= tf) & (r < tf + (1 - tf) / 3)
-    out["test_mask"] = r >= tf + (1 - tf) / 3
+    return {"labels": labels, "train_mask": r < tf, "val_mask": (r >= tf) & (r < tf + (1 - tf) / 3),
+            "test_mask": r >= tf + (1 - tf) / 3}
+
+
+def make_partition(shape, rank, num_parts, seed=0, device='cpu', num_nodes=None, num_edges=None,
+                   num_features=None, num_classes=None, train_fraction=None):
+    """The part dict of one rank -- what ``partition_dict(preprocess(make_dataset(...)), P)[rank]`` returns --
+    built without ever holding the whole normalised adjacency or the whole feature matrix: for graphs the
+    size of ogbn-papers100M (111 M nodes, 1.6 B entries, BASELINE config 4) every rank builds its own slab
+    on its own GPU. The edge keys (8 B per undirected edge) and the degree vector are the only full-graph
+    arrays. Adjacency slab, labels and masks are identical to the full path (tests/test_host_golden.py);
+    the features of a row block come from that block's own seeded stream (the full path draws all rows
+    from one stream), already row-normalised as preprocess() does.
+    """
+    n, e, f, c, tf = SHAPES[shape]
+    n, e, f, c, tf = num_nodes or n, num_edges or e, num_features or f, num_classes or c, train_fraction or tf
+    dev = torch.device(device)
+    P = int(num_parts)
+    s = (n + P - 1) // P
+    r0, r1 = min(rank * s, n), min((rank + 1) * s, n)
+    keys = rmat_undirected(n, e, seed=seed, device=dev)
+    lo, hi = keys // n, keys % n
+    del keys
+    # degree = column sum of (A without loops + I), duplicates summed: graph_utils.sym_normalization
+    deg = torch.ones(n, dtype=torch.float32, device=dev)
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    deg.index_add_(0, lo, ones.expand(lo.numel()))
+    deg.index_add_(0, hi, ones.expand(hi.numel()))
+    d = deg.pow(-0.5)
+    del deg
+    m1, m2 = (lo >= r0) & (lo < r1), (hi >= r0) & (hi < r1)
+    diag = torch.arange(r0, r1, dtype=torch.int64, device=dev)
+    rows = torch.cat([lo[m1], hi[m2], diag])
+    cols = torch.cat([hi[m1], lo[m2], diag])
+    del lo, hi, m1, m2
+    order = torch.argsort((rows - r0) * (s * P) + cols)          # row-major, as coalesce() leaves it
+    rows, cols = rows[order], cols[order]
+    del order
+    vals = (d[rows] * 1.0) * d[cols]                             # (d_i * a_ij) * d_j with a_ij = 1
+    adj = torch.sparse_coo_tensor(torch.stack([rows - r0, cols]), vals, (s, s * P), is_coalesced=True)
+    del rows, cols, d
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed * 1000003 + 17 * rank + 1)
+    if shape == 'cora':
+        feats = (torch.rand(r1 - r0, f, generator=gen, device=dev) < 0.0127).to(torch.float32)
+    else:
+        feats = torch.randn(r1 - r0, f, generator=gen, device=dev)
+    feats = feats / feats.sum(1, keepdim=True).clamp(min=1)
+    if feats.size(0) < s:
+        feats = torch.cat([feats, feats.new_zeros(s - feats.size(0), f)])
+    out = {"adj": adj, "features": feats, "num_nodes": n, "num_edges": 2 * e, "num_classes": c}
+    pad = s * P - n
+    for k, v in _labels_and_masks(n, c, tf, seed, dev).items():
+        out[k] = torch.cat([v, v.new_zeros(pad)]) if pad else v
     return out

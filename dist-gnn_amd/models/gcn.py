@@ -442,7 +442,9 @@ class StagePipeline:
         import time
         sent = self.transfers
 
-        forms = ['bcast', 'allgather'] + (['agpipe'] if feat.size(1) > 32 else [])
+        forms = ['bcast']
+        if self._gather_fits(feat, len(stages)):            # the gathered matrix is P times a block: papers-sized
+            forms += ['allgather'] + (['agpipe'] if feat.size(1) > 32 else [])   # graphs cannot afford it
         if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.75:
             forms.append('needed')
         moved = (self.rows_moved, self.rows_full)
@@ -479,6 +481,15 @@ class StagePipeline:
         DistEnv.env.logger.log(f'pipeline auto {tag} [{feat.size(0)}x{feat.size(1)}] P={len(stages)}: '
                                + ', '.join(f'{f} {times[f] * 1e3:.3f} ms' for f in forms) + f' -> {form}', rank=0)
         return form
+
+    @staticmethod
+    def _gather_fits(feat, P):
+        """The all-gather forms hold H of the whole graph on every rank (per feature width): only while that is
+        at most 1/16 of the device memory (18 GB on an MI355X; a papers100M layer would need 53-106 GiB)."""
+        if not feat.is_cuda:
+            return True
+        need = P * feat.size(0) * ((feat.size(1) + 31) // 32 * 32) * feat.element_size()
+        return need * 16 <= torch.cuda.get_device_properties(feat.device).total_memory
 
     @staticmethod
     def _needed_ok(adj_parts, stages, group):

@@ -98,6 +98,28 @@ def test_part_files_carry_int32_csr_blocks(golden_dir, name, P, tmp_path, monkey
                                   ref_cpu.coo2csr(t.indices()[0].numpy().astype(np.int32), t.size(0)))
 
 
+@pytest.mark.parametrize('P', [1, 3, 8])
+def test_per_rank_part_generation_equals_the_full_path(P):
+    """synthetic.make_partition (what a papers100M-sized run uses: no rank ever holds the whole normalised
+    adjacency or feature matrix) builds the same slab, labels and masks as make_dataset -> preprocess ->
+    partition_dict, bit for bit."""
+    from coo_graph import synthetic, graph_utils, parted_coo_graph
+    kw = dict(seed=3, num_nodes=1001, num_edges=6000)
+    pre = graph_utils.preprocess('x', dict(synthetic.make_dataset('reddit', **kw)), 'GCN')
+    _, parts = parted_coo_graph.partition_dict(pre, P)
+    for r in range(P):
+        mine = synthetic.make_partition('reddit', r, P, **kw)
+        a, b = parts[r]['adj'].coalesce(), mine['adj'].coalesce()
+        assert a.shape == b.shape and torch.equal(a.indices(), b.indices()) and torch.equal(a.values(), b.values())
+        for k in ('labels', 'train_mask', 'val_mask', 'test_mask'):
+            assert torch.equal(parts[r][k], mine[k]), k
+        assert mine['features'].shape == parts[r]['features'].shape and mine['features'].dtype == torch.float32
+        assert mine['num_nodes'] == pre['num_nodes'] and mine['num_classes'] == pre['num_classes']
+        import coo_graph
+        g = coo_graph.Parted_COO_Graph('x', r, P, attr_dict=mine)      # loads like any part dict
+        assert len(g.adj_parts) == P and g.local_num_nodes == (1001 + P - 1) // P
+
+
 def test_synthetic_dataset_schema_and_determinism():
     from coo_graph import synthetic, datasets
     a = synthetic.make_dataset('cora', seed=3)

@@ -32,22 +32,32 @@ def main():
     ap.add_argument('--parts', type=int, default=8)
     ap.add_argument('--rank', type=int, default=0)
     ap.add_argument('--F', default='602,256,41')
+    ap.add_argument('--lean', action='store_true', help='synthetic.make_partition: build only this rank\'s part')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     n = synthetic.SHAPES[args.shape][0]
-    d = synthetic.make_dataset(args.shape, seed=0, device=dev, with_features=False)
-    adj = graph_utils.sym_normalization(d['edge_index'], n)
-    del d
     P = args.parts
     s = (n + P - 1) // P
-    slab = graph_utils.sparse_2d_split(adj, s)[args.rank]
-    slab = torch.sparse_coo_tensor(slab.indices(), slab.values(), (s, s * P), is_coalesced=True)
+    t0 = time.perf_counter()
+    if args.lean:                       # only this rank's part is ever built (papers-sized graphs)
+        part = synthetic.make_partition(args.shape, args.rank, P, seed=0, device=dev)
+        slab = part['adj']
+        del part
+    else:
+        d = synthetic.make_dataset(args.shape, seed=0, device=dev, with_features=False)
+        adj = graph_utils.sym_normalization(d['edge_index'], n)
+        del d
+        slab = graph_utils.sparse_2d_split(adj, s)[args.rank]
+        slab = torch.sparse_coo_tensor(slab.indices(), slab.values(), (s, s * P), is_coalesced=True)
+        del adj
+    torch.cuda.synchronize()
+    print(f'# part built in {time.perf_counter() - t0:.1f} s, peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
     blocks = graph_utils.sparse_2d_split(slab, s, split_dim=1)
     A_slab = spmm_cpp.CsrBlock.from_coo(slab)
     A_blk = [spmm_cpp.CsrBlock.from_coo(b) for b in blocks]
     print(f'# {args.shape} rank {args.rank} of {P}: slab {s} x {s * P}, nnz {A_slab.nnz}', flush=True)
     for F in [int(x) for x in args.F.split(',')]:
-        H = spmm_cpp.pad_rows(torch.rand(s * P, F, device=dev))
+        H = torch.rand(s * P, spmm_cpp.padded_width(F), device=dev)      # already at the padded pitch
         z1 = torch.zeros(s, F, device=dev)
         z2 = torch.zeros(s, F, device=dev)
 
@@ -60,7 +70,10 @@ def main():
         z1.zero_(); per_block(); z2.zero_(); fused()
         same = torch.equal(z1, z2)
         tb, tf = timed(per_block), timed(fused)
-        print(f'F={F:4d}  {P} block SpMMs {tb:7.3f} ms   one slab SpMM {tf:7.3f} ms   same bits: {same}', flush=True)
+        print(f'F={F:4d}  {P} block SpMMs {tb:7.3f} ms   one slab SpMM {tf:7.3f} ms   same bits: {same}   '
+              f'(gathered H: {H.numel() * 4 / 2**30:.1f} GiB)', flush=True)
+        del H, z1, z2
+        torch.cuda.empty_cache()
 
 
 if __name__ == '__main__':

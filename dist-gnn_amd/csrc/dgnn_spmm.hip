@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 // is (columns per block) x 256 B instead of whole B rows.
 // ---------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int SEG_MAX = 256;   // LDS strip of a 16-lane group, in entries (8-lane groups: half)
+constexpr int SEG_MAX = 256;   // LDS strip of a 16-lane group, in entries (32-lane groups: 512, 8-lane groups: 128)
 
 // C-side access helpers: VWC floats per access, guarded per element against F.
 template <int VWC>
@@ -289,13 +289,13 @@ __device__ __forceinline__ void gather_round(const uint2* ent, int j, const char
   }
 }
 
-// Instruction budget of the inner loop (what bounds this kernel once gathers are L2-resident:
-// PMC showed TA 56 % busy, L2 latency 250 cycles, and the SIMDs saturated by ~14 VALU/LDS
-// instructions per gathered float4): a batch of 16 (col, val) entries is turned ONCE into
-// (32-bit byte offset of the B row, alpha*val) pairs and parked in a wave-private LDS strip;
-// every lane of the group then reads two entries per ds_read_b128 at a group-uniform address
-// (LDS broadcast), adds its own lane offset, and issues global_load_dwordx4 with the scalar
-// base of B (saddr form). Per entry and lane: 1/2 LDS read + 1 add + 1 load + 2 packed FMAs.
+// Instruction budget of the inner loop. With the gathers L2-resident the kernel is bound by the texture-
+// address unit (PMC: TA 86-88 % busy, ~21 TA cycles per wave-level global_load_dwordx4 against a floor of
+// 16), so everything else has to stay out of its way: a strip of (col, val) entries is turned ONCE into
+// (32-bit byte offset of the B row, alpha*val) pairs and parked in a group-private LDS strip; every lane
+// of the group then reads two entries per ds_read_b128 at a group-uniform address (LDS broadcast), adds
+// its own lane offset, and issues global_load_dwordx4 with the scalar base of B (saddr form). Per entry
+// and lane: 1/2 LDS read + 1 add + 1 load + 2 packed FMAs.
 template <int L, int U, int VWC, bool WIDE>
 __global__ __launch_bounds__(256) void spmm_stage_kernel(
     const int4* __restrict__ seg, int32_t nseg, uint32_t nsegblocks,
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
     float* __restrict__ P, int64_t ldp, int32_t F, float alpha, uint32_t k) {
   constexpr int G = 64 / L;
-  constexpr int SEGM = SEG_MAX * L / 16;        // strip length: 256 entries (L = 16), 128 (L = 8)
+  constexpr int SEGM = SEG_MAX * L / 16;        // strip length: 16 entries per lane of the group
   static_assert(U % 2 == 0, "entries are read two per ds_read_b128");
   __shared__ uint2 ent_all[4][G][SEGM];         // (row offset or column, alpha*val) of the group's run
   const int lane = threadIdx.x & 63;
@@ -340,10 +340,9 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   const bool live = s.x >= 0;                   // row -1: an unused slot of a list sized by an upper bound
   const int kb = s.y, ke = s.z;
   const bool direct = s.w < 0;
-  // lanes past the padded width gather a valid float4 (the row's last one) and never store it
+  // lanes past the padded width (last chunk of a width that is no multiple of the chunk) gather nothing
   const bool gathers = fbase < (int)ldb;
-  const int fgather = min(fbase, (int)ldb - 4);
-  const uint32_t loff = (uint32_t)fgather * 4u;
+  const uint32_t loff = (uint32_t)fbase * 4u;
   const uint32_t ldb_bytes = (uint32_t)ldb * 4u;
   const char* const Bbytes = reinterpret_cast<const char*>(B);
 
@@ -514,11 +513,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // Work plan of the stage kernel for a block nobody planned, built on the device in three small passes over
 // the rows -- the same plan shape a host-built dgnn_plan has: `ns` column-block stages; per stage one
 // segment per non-empty (row, column block) run, runs longer than `piece` cut into pieces (-> partial rows
-// -> merge); inside a stage everything grouped by length class (bit length of the run), longest class
+// -> merge); inside a stage everything grouped by length class (len_class below), longest class
 // first, so long runs start early and the runs that share a wave have similar lengths. The lists are
 // sized by upper bounds (the host never learns the counts): unused segment slots keep row = -1, unused
-// cut slots count = 0. Header `hdr`: per stage PLAN_HDR_STAGE ints = [0, 32) class counts, [32, 64) write
-// cursors, [64] cut runs; then [PLAN_HDR_NPART] partial rows. Positions come from atomic counters, so the
+// cut slots count = 0. Header `hdr`: per stage PLAN_HDR_STAGE ints = [0, NCLS) class counts, [NCLS, 2 NCLS)
+// write cursors, [2 NCLS] cut runs; then [PLAN_HDR_NPART] partial rows. Positions come from atomic counters, so the
 // list order varies from run to run; the result does not (a run, or a piece, is one chain with one
 // writer; pieces are merged in piece order).
 constexpr int PLAN_MAX_STAGES = 16;

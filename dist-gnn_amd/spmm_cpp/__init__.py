@@ -33,16 +33,41 @@ if not os.path.exists(_LIB_PATH):
 _lib = ctypes.CDLL(_LIB_PATH)
 
 _p, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
-_lib.dgnn_version.restype = ctypes.c_int
+
+
+class _CPlan(ctypes.Structure):          # struct dgnn_plan (include/dgnn_spmm.h)
+    _fields_ = [('nstage', _i32), ('seg', _p), ('stage_seg_off', _p), ('cut', _p),
+                ('stage_cut_off', _p), ('npartial', _i64), ('max_seg_len', _i32)]
+
+
+class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn_spmm.h)
+    _fields_ = [('nstage', _i32), ('piece', _i32), ('hdr_ints', _i64), ('nseg_max', _i64), ('ncut_max', _i64),
+                ('npartial_max', _i64), ('ws_ints', _i64)]
+
+
+_pi64 = ctypes.POINTER(ctypes.c_int64)
+_SIGNATURES = {                          # argument types, in the order of include/dgnn_spmm.h; all return int
+    'dgnn_version': [],
+    'dgnn_set_variant': [ctypes.c_int],
+    'dgnn_get_variant': [],
+    'dgnn_prof_begin': [],
+    'dgnn_prof_end': [ctypes.POINTER(ctypes.c_double), _pi64, ctypes.POINTER(ctypes.c_double), _pi64],
+    'dgnn_coo2csr_i32': [_p, _i64, _i32, _p, _p],
+    'dgnn_idx_i64_to_i32': [_p, _i64, _p, _p],
+    'dgnn_pad_rows_f32': [_p, _i64, _p, _i64, _i32, _i32, _p],
+    'dgnn_gather_rows_f32': [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p],
+    'dgnn_spmm_csr_f32': [_p, _p, _p, _i32, _i32, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+    'dgnn_spmm_coo_f32': [_p, _p, _p, _i32, _i32, _i64, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+    'dgnn_coo_aligned_workspace': [_i32, _i32, _i64, _i64, _pi64, _pi64],
+    'dgnn_spmm_coo_aligned_f32': [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+    'dgnn_plan_layout_for': [_i32, _i32, _i64, _i64, _i32, _i32, ctypes.POINTER(_CLayout)],
+    'dgnn_plan_build': [_p, _p, _i32, _i32, ctypes.POINTER(_CLayout), _p, _p],
+    'dgnn_spmm_plan_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+}
+for _name, _args in _SIGNATURES.items():
+    getattr(_lib, _name).argtypes = _args
+    getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_lib.dgnn_coo2csr_i32.argtypes = [_p, _i64, _i32, _p, _p]
-_lib.dgnn_idx_i64_to_i32.argtypes = [_p, _i64, _p, _p]
-_lib.dgnn_spmm_csr_f32.argtypes = [_p, _p, _p, _i32, _i32, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p]
-_lib.dgnn_spmm_coo_f32.argtypes = [_p, _p, _p, _i32, _i32, _i64, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p]
-_lib.dgnn_set_variant.argtypes = [ctypes.c_int]
-for _f in ('dgnn_coo2csr_i32', 'dgnn_idx_i64_to_i32', 'dgnn_spmm_csr_f32', 'dgnn_spmm_coo_f32',
-           'dgnn_set_variant', 'dgnn_get_variant'):
-    getattr(_lib, _f).restype = ctypes.c_int
 
 lib = _lib  # exposed for tests that call the C ABI directly
 
@@ -95,7 +120,6 @@ def _scratch(kind, count, dtype, dev):
     return buf
 
 
-
 def spmm_cusparse(A_row_idx, A_col_idx, A_values, A_row, A_col, B, C, alpha, beta):
     """C <- alpha * A @ B + beta * C in place; A is row-sorted COO (int32 indices, fp32 values).
 
@@ -113,6 +137,8 @@ def spmm_cusparse(A_row_idx, A_col_idx, A_values, A_row, A_col, B, C, alpha, bet
     bptr, ldb = _dense(B, 'B')
     cptr, ldc = _dense(C, 'C')
     n, m, F = int(A_row), int(A_col), C.size(1)
+    if not (0 <= n < 2 ** 31 and 0 <= m < 2 ** 31 and nnz < 2 ** 31):
+        raise RuntimeError('spmm_cpp: block exceeds int32 indexing')
     if B.size(0) != m or C.size(0) != n or B.size(1) != F:
         raise RuntimeError(f'spmm_cpp: shape mismatch A[{n}x{m}] B{tuple(B.shape)} C{tuple(C.shape)}')
     if not (A_values.device == A_row_idx.device == A_col_idx.device == B.device == C.device):
@@ -213,20 +239,7 @@ def set_variant(v):
     _check(_lib.dgnn_set_variant(int(v)), 'set_variant')
 
 
-
-
 # --------------------------------------------------------------------------- fast path: work plan
-class _CPlan(ctypes.Structure):          # struct dgnn_plan (include/dgnn_spmm.h)
-    _fields_ = [('nstage', _i32), ('seg', _p), ('stage_seg_off', _p), ('cut', _p),
-                ('stage_cut_off', _p), ('npartial', _i64), ('max_seg_len', _i32)]
-
-
-_lib.dgnn_pad_rows_f32.argtypes = [_p, _i64, _p, _i64, _i32, _i32, _p]
-_lib.dgnn_pad_rows_f32.restype = ctypes.c_int
-_lib.dgnn_spmm_plan_f32.argtypes = [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64,
-                                    _i32, _f32, _f32, _p]
-_lib.dgnn_spmm_plan_f32.restype = ctypes.c_int
-
 PIECE_LEN = 4096             # longest run one lane group walks (strip by strip); longer runs are cut and merged
 
 
@@ -247,14 +260,6 @@ def pad_rows(src, dst=None):
     with torch.cuda.device(src.device):
         _check(_lib.dgnn_pad_rows_f32(sptr, lds, dptr, ldd, n, F, _stream(src)), 'pad_rows')
     return dst
-
-
-_lib.dgnn_spmm_coo_aligned_f32.argtypes = [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p]
-_lib.dgnn_coo_aligned_workspace.argtypes = [_i32, _i32, _i64, _i64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
-_lib.dgnn_coo_aligned_workspace.restype = ctypes.c_int
-_lib.dgnn_spmm_coo_aligned_f32.restype = ctypes.c_int
-_lib.dgnn_gather_rows_f32.argtypes = [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]
-_lib.dgnn_gather_rows_f32.restype = ctypes.c_int
 
 
 def gather_rows(src, idx, dst=None):
@@ -370,17 +375,6 @@ class SegPlan:
         if self._partial is None or self._partial.numel() < need:
             self._partial = torch.empty(need, dtype=torch.float32, device=dev)
         return self._partial
-
-
-class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn_spmm.h)
-    _fields_ = [('nstage', _i32), ('piece', _i32), ('hdr_ints', _i64), ('nseg_max', _i64), ('ncut_max', _i64),
-                ('npartial_max', _i64), ('ws_ints', _i64)]
-
-
-_lib.dgnn_plan_layout_for.argtypes = [_i32, _i32, _i64, _i64, _i32, _i32, ctypes.POINTER(_CLayout)]
-_lib.dgnn_plan_layout_for.restype = ctypes.c_int
-_lib.dgnn_plan_build.argtypes = [_p, _p, _i32, _i32, ctypes.POINTER(_CLayout), _p, _p]
-_lib.dgnn_plan_build.restype = ctypes.c_int
 
 
 class DevicePlan:

@@ -48,3 +48,17 @@ def test_binding_rejects_cpu_tensors():
     assert spmm_cpp.default_stage_count(2449029, 2449029, 126167309, 100) == 2    # products: capped by run length
     assert spmm_cpp.default_piece_len(114848857, 4) == 4096 and spmm_cpp.default_piece_len(1819992, 1) == 256
     assert spmm_cpp.default_piece_len(1000, 1) == 128
+
+
+def test_binding_signatures_match_the_header():
+    """The ctypes stub declares every entry point of the header with the same number of arguments."""
+    import spmm_cpp
+    txt = open(os.path.join(ROOT, 'include', 'dgnn_spmm.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    txt = re.sub(r'//[^\n]*', '', txt)
+    protos = {m.group(1): m.group(2) for m in re.finditer(r'\b(dgnn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', txt)}
+    assert set(protos) - {'dgnn_last_error'} == set(spmm_cpp._SIGNATURES)
+    for name, args in spmm_cpp._SIGNATURES.items():
+        decl = protos[name].strip()
+        count = 0 if decl in ('', 'void') else decl.count(',') + 1
+        assert count == len(args), f'{name}: header has {count} arguments, the stub {len(args)}'

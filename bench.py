@@ -143,6 +143,7 @@ def main():
                          "travel through host memory): checks the flow, the number is not a result")
     ap.add_argument('--transform-first', action='store_true',
                     help='opt-in A_hat (H W) ordering for layers with F_out < F_in (re-associated fp32; not the headline)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra transform-first epochs after the timed region')
     args = ap.parse_args()
     layers = args.layers or {'reddit': 2, 'products': 3, 'cora': 2, 'papers': 4}[args.workload]
     if args.model in ('AdaptiveGCN', 'CachedGCN'):
@@ -256,6 +257,25 @@ def main():
         comm = dict(form=pipe.describe(), recv_bytes_per_rank_per_step=int(wire), exposed_ms_per_step=exposed,
                     recv_GBps_if_fully_exposed=round(wire / max(exposed, 1e-6) / 1e6, 1),
                     xgmi_link_peak_GBps=153.0, needed_rows_fraction=(round(moved / full, 4) if full else None))
+    # Beside the headline (never part of it): the same epochs with the opt-in A_hat (H W) ordering, in which a
+    # layer with F_out < F_in aggregates at the narrower width (re-associated fp32, <= 1e-5).
+    alt = None
+    if not args.transform_first and not args.no_alt and args.model == 'GCN':
+        os.environ['DGNN_TRANSFORM_FIRST'] = '1'
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        ta = time.perf_counter()
+        k_alt = min(args.steps, 5)
+        for _ in range(k_alt):
+            step()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        os.environ['DGNN_TRANSFORM_FIRST'] = '0'
+        alt = dict(transform_first_ms_per_step=round(float(t.item()) / k_alt * 1e3, 3), steps=k_alt,
+                   note='opt-in DGNN_TRANSFORM_FIRST=1, same model and data; not the headline')
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         cpu = cpu_baseline(g, widths, args.cpu_budget, s)
@@ -272,7 +292,7 @@ def main():
                        "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
                        "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),
                        "scale": args.scale},
-            "roofline": roofline, "cpu_baseline": cpu, "gpu_ms_per_step": breakdown, "comm": comm,
+            "roofline": roofline, "cpu_baseline": cpu, "gpu_ms_per_step": breakdown, "comm": comm, "alt": alt,
             "final_loss": round(loss_val, 4), "setup_s": round(t_build, 1),
         }
         print(json.dumps(out), flush=True)

@@ -260,7 +260,8 @@ def main():
     # Beside the headline (never part of it): the same epochs with the opt-in A_hat (H W) ordering, in which a
     # layer with F_out < F_in aggregates at the narrower width (re-associated fp32, <= 1e-5).
     alt = None
-    if not args.transform_first and not args.no_alt and args.model == 'GCN':
+    if world == 1 and not args.transform_first and not args.no_alt and args.model == 'GCN':   # one GPU only: the
+        # multi-GPU runs execute nothing beyond the headline measurement
         os.environ['DGNN_TRANSFORM_FIRST'] = '1'
         for _ in range(2):
             step()

@@ -16,19 +16,19 @@ timeout -k 10 300 python bench.py > "$out/bench.json" 2> "$out/bench.err" || exi
 echo "bench done"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$raw/kt" -- \
-    python bench.py --cpu-budget 0 > "$out/bench_under_rocprof.json" 2> "$out/rocprof_kt.err" || exit 2
+    python bench.py --no-alt --cpu-budget 0 > "$out/bench_under_rocprof.json" 2> "$out/rocprof_kt.err" || exit 2
 cp "$(find "$raw/kt" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv" || exit 3
 python tools/pmc_summary.py "$raw/kt" spmm_ > "$out/kernel_durations.txt"
 python tools/pmc_summary.py "$raw/kt" merge_ >> "$out/kernel_durations.txt"
 echo "kernel trace done"
 
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$raw/fetch" -- \
-    python bench.py --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err" || exit 4
+    python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err" || exit 4
 python tools/pmc_summary.py "$raw/fetch" spmm_stage > "$out/pmc_fetch_size.txt"
 echo "fetch pass done"
 
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$raw/write" -- \
-    python bench.py --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_write_bench.json" 2> "$out/pmc_write.err" || exit 5
+    python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_write_bench.json" 2> "$out/pmc_write.err" || exit 5
 python tools/pmc_summary.py "$raw/write" spmm_stage > "$out/pmc_write_size.txt"
 echo "write pass done"
 rm -rf "$raw"

@@ -113,7 +113,27 @@ def cpu_baseline(g, widths, budget_s, rank_rows):
         t0 = time.perf_counter()
         ref_cpu.spmm_csr(rowptr, col, val, B, C, 1.0, 1.0, threads=threads)
         total_t += time.perf_counter() - t0
+    # Beside it, the reference's own CPU path -- models/gcn.py:13 falls back to ``C.addmm_(A, B)``, ATen's
+    # sparse addmm -- on a shorter row prefix (it walks the nonzeros on one thread), and a check that the
+    # port gives the same bits there.
+    r2 = max(1, min(int(torch.searchsorted(rp, torch.tensor([3_000_000], device=rp.device)).item()), r1))
+    k2 = int(rp[r2].item())
+    A_cpu = torch.sparse_coo_tensor(idx[:, :k2].cpu(), adj.values()[:k2].cpu(), (r2, m)).coalesce()
+    aten_t, same = 0.0, True
+    for F in widths:
+        B = torch.from_numpy(rng.random((m, F), dtype=np.float32))
+        C = torch.zeros(r2, F)
+        t0 = time.perf_counter()
+        C.addmm_(A_cpu, B)
+        aten_t += time.perf_counter() - t0
+        C2 = np.zeros((r2, F), dtype=np.float32)
+        ref_cpu.spmm_csr(rowptr[:r2 + 1], col[:k2], val[:k2], B.numpy(), C2, 1.0, 1.0, threads=threads)
+        same = same and bool(np.array_equal(C.numpy(), C2))
+    aten = dict(value=round(len(widths) * k2 / aten_t / 1e9, 4), unit='GEdges/s', threads=torch.get_num_threads(),
+                sample=f'torch C.addmm_(A, B) on the CPU, first {r2} rows ({k2} nonzeros), same widths, {aten_t:.1f} s',
+                port_gives_the_same_bits=same)
     return dict(value=round(len(widths) * k1 / total_t / 1e9, 4), unit='GEdges/s', cores=threads, kind='port',
+                reference_fallback_addmm=aten,
                 sample=f'oracle/spmm_ref.c (ATen CPU sparse addmm chain, fmaf; rows dealt to {threads} OpenMP '
                        f'threads, same bits as one thread) on the first {r1} rows '
                        f'({k1} nonzeros) of the same normalised graph, SpMM widths {list(widths)} of one epoch, '

@@ -236,6 +236,12 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # the last step's training loss over ALL training nodes (each rank's loss is a mean over its own): the
+    # number that must not depend on N
+    cnt = float(g.local_train_mask.sum().item())
+    t = torch.tensor([loss_val * cnt, cnt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    global_loss = float(t[0].item() / max(t[1].item(), 1.0))
 
     # ---- figures
     dims = [g.features.size(1)] + [args.hidden] * (layers - 1) + [g.num_classes]
@@ -314,7 +320,7 @@ def main():
                        "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),
                        "scale": args.scale},
             "roofline": roofline, "cpu_baseline": cpu, "gpu_ms_per_step": breakdown, "comm": comm, "alt": alt,
-            "final_loss": round(loss_val, 4), "setup_s": round(t_build, 1),
+            "final_loss": round(loss_val, 4), "final_loss_all_ranks": round(global_loss, 6), "setup_s": round(t_build, 1),
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

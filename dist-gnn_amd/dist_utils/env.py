@@ -8,7 +8,7 @@ logger, timer, store and the ``DistEnv.env`` singleton -- with these deliberate 
     1-GPU box silently trains on the CPU. Here a 'nccl' backend (or any visible GPU with a
     non-gloo backend) selects ``cuda:LOCAL_RANK``; 'gloo' selects the CPU, unless DGNN_GLOO_CUDA=1
     (rehearsal: several ranks share the visible GPUs, the HIP kernels run, and the blocks travel
-    through gloo's host staging -- how the N > 1 path is exercised on a one-GPU box).
+    through host copies, dist_utils/host_staged.py -- how the N > 1 path is exercised on a one-GPU box).
   * the P(P-1)/2 two-rank groups (env.py:50-54) are created lazily on first use: the GCN path
     never touches them and each costs an RCCL communicator.
   * an already-initialised default process group (torchrun) is reused.
@@ -68,6 +68,9 @@ class DistEnv:
                 kwargs['device_id'] = self.device
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size,
                                     init_method='env://', **kwargs)
+        if self.backend == 'gloo' and self.device.type == 'cuda':
+            from . import host_staged
+            host_staged.install()          # rehearsal: GPU tensors travel through host copies (see that module)
         self.world_group = dist.group.WORLD
         self.p2p_group_dict = _LazyPairGroups()
 

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
     const int4* __restrict__ seg, int32_t nseg, uint32_t nsegblocks,
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-    float* __restrict__ P, int64_t ldp, int32_t F, float alpha, uint32_t k) {
+    float* __restrict__ P, int64_t ldp, int32_t F, float alpha, uint32_t k, int fresh) {
   constexpr int G = 64 / L;
   constexpr int SEGM = SEG_MAX * L / 16;        // strip length: 16 entries per lane of the group
   static_assert(U % 2 == 0, "entries are read two per ds_read_b128");
@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
 
   float* const dst = direct ? (C + (int64_t)s.x * ldc + fbase) : (P + (int64_t)s.w * ldp + fbase);
   f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-  if (live && direct) c_load<VWC>(dst, fbase, F, a01, a23);   // pieces start from 0, direct runs from C
+  // pieces start from 0, direct runs from C -- unless the caller knows C holds zeros (`fresh`: the first
+  // stage after a zero fill), which saves one read pass over C
+  if (live && direct && !fresh) c_load<VWC>(dst, fbase, F, a01, a23);
 
   // A run is walked strip by strip (SEGM entries). Per strip --
   // Phase 1: the strip's (col, val) stream -- cold data, read once, HBM/Infinity-Cache latency -- is
@@ -728,7 +730,7 @@ bool overlap(const float* B, int64_t rows_b, int64_t ldb, const float* C, int64_
 template <int L, int U>
 int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_t* col, const float* val,
                  const float* B, int64_t ldb, float* C, int64_t ldc, float* P, int64_t ldp,
-                 int32_t F, float alpha, hipStream_t s) {
+                 int32_t F, float alpha, bool fresh, hipStream_t s) {
   constexpr int G = 64 / L;
   int64_t nsegblocks = ((int64_t)nseg + 4 * G - 1) / (4 * G);         // 4 waves x G groups per workgroup
   const int64_t nchunks = (ldb / 4 + L - 1) / L;
@@ -741,7 +743,7 @@ int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_
   ProfScope prof(s, 0);
 #define DGNN_STAGE(VWC, WIDE)                                                                             \
   hipLaunchKernelGGL((spmm_stage_kernel<L, U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
-                     (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha, k)
+                     (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha, k, fresh ? 1 : 0)
   if (wide) { if (vwc == 4) DGNN_STAGE(4, true); else if (vwc == 2) DGNN_STAGE(2, true); else DGNN_STAGE(1, true); }
   else { if (vwc == 4) DGNN_STAGE(4, false); else if (vwc == 2) DGNN_STAGE(2, false); else DGNN_STAGE(1, false); }
 #undef DGNN_STAGE
@@ -934,10 +936,10 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
   return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
 }
 
-int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
-                       int32_t n, int32_t m, const float* B, int64_t ldb,
-                       float* C, int64_t ldc, float* partial, int64_t ldp,
-                       int32_t F, float alpha, float beta, void* stream) {
+static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float* val,
+                          int32_t n, int32_t m, const float* B, int64_t ldb,
+                          float* C, int64_t ldc, float* partial, int64_t ldp,
+                          int32_t F, float alpha, float beta, bool c_is_zero, void* stream) {
   if (!plan) return fail(DGNN_E_BADARG, "spmm_plan: null plan%s", "");
   if (n < 0 || m < 0 || F < 0) return fail(DGNN_E_BADARG, "spmm_plan: negative size%s", "");
   if (n == 0 || F == 0) return DGNN_OK;
@@ -962,6 +964,7 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
   if (ncut > 0 && (!partial || !plan->cut || ldp < ldb || ldp % 4 != 0 || !aligned(partial, 16)))
     return fail(DGNN_E_BADARG, "spmm_plan: cut segments need a 16-byte aligned partial buffer with ldp >= ldb, ldp %% 4 == 0%s", "");
   const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : ((ldc % 2 == 0 && aligned(C, 8)) ? 2 : 1);
+  bool fresh = c_is_zero || beta == 0.f;       // C holds zeros until the first stage kernel has run
   const bool wide = ((uint64_t)(m > 0 ? m : 1) * (uint64_t)ldb * 4u) >= 0xffffff00ull || g_variant == 2;   // 32-bit row offsets?
   for (int32_t st = 0; st < plan->nstage; ++st) {
     const int64_t s0 = plan->stage_seg_off[st], s1 = plan->stage_seg_off[st + 1];
@@ -974,7 +977,7 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
       // shares they are 5-25 % slower at every width measured. Kept behind the variant knob for A/B runs.
       const bool narrow = (g_variant == 8);
       if (narrow)
-        rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s);
+        rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s);
       else {
         // Gathers in flight per lane: 4 while one stage's slice of B fits the 256 MiB Infinity Cache, 2 when
         // the rows come out of HBM (measured: products/papers shapes -6..-10 % with 2, Reddit -4 % with 4
@@ -990,12 +993,13 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
         const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100
                       : (plan->max_seg_len > 16384 || lane_groups < 200000) ? 8
                       : (stage_bytes <= (256ll << 20) ? 4 : 2);
-#define DGNN_LAUNCH(LL, UU) launch_stage<LL, UU>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, s)
+#define DGNN_LAUNCH(LL, UU) launch_stage<LL, UU>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s)
         if (wide_group) rc = (u == 2) ? DGNN_LAUNCH(32, 2) : (u == 4) ? DGNN_LAUNCH(32, 4) : (u == 6) ? DGNN_LAUNCH(32, 6) : DGNN_LAUNCH(32, 8);
         else rc = (u == 2) ? DGNN_LAUNCH(16, 2) : (u == 4) ? DGNN_LAUNCH(16, 4) : (u == 6) ? DGNN_LAUNCH(16, 6) : DGNN_LAUNCH(16, 8);
 #undef DGNN_LAUNCH
       }
       if (rc != DGNN_OK) return rc;
+      fresh = false;
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
     if (p1 > p0) {
@@ -1010,6 +1014,20 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
     }
   }
   return DGNN_OK;
+}
+
+int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
+                       int32_t n, int32_t m, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, float* partial, int64_t ldp,
+                       int32_t F, float alpha, float beta, void* stream) {
+  return spmm_plan_impl(plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, false, stream);
+}
+
+int dgnn_spmm_plan_zeroed_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
+                              int32_t n, int32_t m, const float* B, int64_t ldb,
+                              float* C, int64_t ldc, float* partial, int64_t ldp,
+                              int32_t F, float alpha, void* stream) {
+  return spmm_plan_impl(plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, 1.f, true, stream);
 }
 
 }  // extern "C"

@@ -146,12 +146,14 @@ def _csr_block(A):
     return blk
 
 
-def spmm(A, B, C):
-    """C += A @ B in place (alpha = beta = 1, as gcn.py:11 calls spmm_cusparse)."""
+def spmm(A, B, C, fresh=False):
+    """C += A @ B in place (alpha = beta = 1, as gcn.py:11 calls spmm_cusparse). ``fresh``: C was zero-filled
+    a moment ago and nothing has been added yet (the first stage of an aggregation): the kernel then
+    skips reading it. Same result either way."""
     if _spmm_override is not None:
         return _spmm_override(A, B, C)
     import spmm_cpp
-    spmm_cpp.aggregate(_csr_block(A), B, C)
+    spmm_cpp.aggregate(_csr_block(A), B, C, z_is_zero=fresh)
 
 
 class StagePipeline:
@@ -259,16 +261,16 @@ class StagePipeline:
             if keep is not None:
                 keep['gathered'] = gathered
             with timer.timing_cuda('spmm'):
-                spmm(slab, gathered[:, :F] if ld != F else gathered, z)
+                spmm(slab, gathered[:, :F] if ld != F else gathered, z, fresh=True)
             return z
         members = sorted(src for src, _ in stages)
-        for src, blk in stages:
+        for i, (src, blk) in enumerate(stages):
             pos = members.index(src)
             block = gathered[pos * s:(pos + 1) * s, :F]
             if keep is not None and src != rank:
                 keep[src] = block
             with timer.timing_cuda('spmm'):
-                spmm(adj_parts[blk], block, z)
+                spmm(adj_parts[blk], block, z, fresh=(i == 0))
         return z
 
     def _run_agpipe(self, adj_parts, feat, stages, group, z, chunks=2):
@@ -311,11 +313,11 @@ class StagePipeline:
             zc = z[:, c0:c1]
             with timer.timing_cuda('spmm'):
                 if fused:
-                    spmm(slab, gathered[:, :w], zc)
+                    spmm(slab, gathered[:, :w], zc, fresh=True)
                 else:
-                    for src, blk in stages:
+                    for i, (src, blk) in enumerate(stages):
                         pos = members.index(src)
-                        spmm(adj_parts[blk], gathered[pos * s:(pos + 1) * s, :w], zc)
+                        spmm(adj_parts[blk], gathered[pos * s:(pos + 1) * s, :w], zc, fresh=(i == 0))
         self.transfers += P
         return z
 
@@ -368,7 +370,7 @@ class StagePipeline:
             if keep is not None and src != rank:
                 keep[src] = block
             with timer.timing_cuda('spmm', cs):
-                spmm(adj_parts[blk], block, z)
+                spmm(adj_parts[blk], block, z, fresh=(i == 0))
         return z
 
     def _run_needed(self, adj_parts, feat, stages, group, z):
@@ -423,12 +425,12 @@ class StagePipeline:
             self.transfers += 1
             if src == rank:
                 with timer.timing_cuda('spmm'):
-                    spmm(adj_parts[blk], feat, z)
+                    spmm(adj_parts[blk], feat, z, fresh=(i == 0))
                 continue
             self.rows_full += nr.block_rows
             if buf is not None:
                 with timer.timing_cuda('spmm'):
-                    spmm(nr.blocks[src], buf[:, :F] if ld != F else buf, z)
+                    spmm(nr.blocks[src], buf[:, :F] if ld != F else buf, z, fresh=(i == 0))
         for w in sends:                       # the send buffer is reused by the next aggregation
             w.wait()
         return z
@@ -528,7 +530,7 @@ class StagePipeline:
         plain = policy is None
         if plain and len(stages) == 1 and stages[0][0] == rank:
             with timer.timing_cuda('spmm'):
-                spmm(adj_parts[stages[0][1]], feat, z)
+                spmm(adj_parts[stages[0][1]], feat, z, fresh=True)
             return z
 
         cacheable = (plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1')
@@ -538,11 +540,11 @@ class StagePipeline:
             if hit is not None and hit[0] == self._tensor_key(orig):
                 if 'gathered' in hit[1]:
                     with timer.timing_cuda('spmm'):
-                        spmm(adj_parts.slab, hit[1]['gathered'][:, :feat.size(1)], z)
+                        spmm(adj_parts.slab, hit[1]['gathered'][:, :feat.size(1)], z, fresh=True)
                     return z
-                for src, blk in stages:
+                for i, (src, blk) in enumerate(stages):
                     with timer.timing_cuda('spmm'):
-                        spmm(adj_parts[blk], feat if src == rank else hit[1][src], z)
+                        spmm(adj_parts[blk], feat if src == rank else hit[1][src], z, fresh=(i == 0))
                 return z
         keep = {} if cacheable else None
 

@@ -63,6 +63,7 @@ _SIGNATURES = {                          # argument types, in the order of inclu
     'dgnn_plan_layout_for': [_i32, _i32, _i64, _i64, _i32, _i32, ctypes.POINTER(_CLayout)],
     'dgnn_plan_build': [_p, _p, _i32, _i32, ctypes.POINTER(_CLayout), _p, _p],
     'dgnn_spmm_plan_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+    'dgnn_spmm_plan_zeroed_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
 }
 for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
@@ -442,9 +443,10 @@ def _plan_for(A, F):
     return plans[ns]
 
 
-def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None):
+def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, c_is_zero=False):
     """C <- alpha * A @ B[:, :F] + beta * C, fast path. ``B`` is a padded feature block from
-    ``pad_rows`` (16-byte aligned rows); ``C`` is any row-major [n, F] fp32 matrix."""
+    ``pad_rows`` (16-byte aligned rows); ``C`` is any row-major [n, F] fp32 matrix.
+    ``c_is_zero`` (with beta = 1): the caller has just zero-filled C, so the kernel need not read it."""
     bptr, ldb = _dense(B, 'B')
     cptr, ldc = _dense(C, 'C')
     F = C.size(1)
@@ -457,12 +459,16 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None):
     dev = C.device
     P = plan.partial(ldb, dev)
     args = (ctypes.byref(plan.c), A.col.data_ptr(), A.val.data_ptr(), A.n, A.m, bptr, ldb, cptr, ldc,
-            P.data_ptr(), ldb, F, float(alpha), float(beta))
+            P.data_ptr(), ldb, F, float(alpha))
+    if c_is_zero and beta == 1.0:
+        fn = _lib.dgnn_spmm_plan_zeroed_f32
+    else:
+        fn, args = _lib.dgnn_spmm_plan_f32, args + (float(beta),)
     if torch.cuda.current_device() == dev.index:         # the usual case: no device switch to pay for
-        rc = _lib.dgnn_spmm_plan_f32(*args, _stream(C))
+        rc = fn(*args, _stream(C))
     else:
         with torch.cuda.device(dev):
-            rc = _lib.dgnn_spmm_plan_f32(*args, _stream(C))
+            rc = fn(*args, _stream(C))
     _check(rc, 'spmm_plan')
 
 
@@ -480,14 +486,15 @@ def _pad_buffer(n, ld, dev):
     return buf
 
 
-def aggregate(A, H, Z):
+def aggregate(A, H, Z, z_is_zero=False):
     """Z += A @ H for a CsrBlock A: the SpMM of one pipeline stage (models/gcn.py:28-29).
     H is any row-major [m, F] fp32 matrix; unless its rows already are 128-byte aligned it is
-    first copied into a padded block (dgnn_pad_rows_f32)."""
+    first copied into a padded block (dgnn_pad_rows_f32). ``z_is_zero``: Z was just zero-filled (the
+    first stage of an aggregation), so it is written without being read."""
     F = Z.size(1)
     if not (H.dim() == 2 and H.size(1) == F):
         raise RuntimeError(f'aggregate: H{tuple(H.shape)} does not match Z{tuple(Z.shape)}')
     if H.stride(0) != padded_width(F) or H.data_ptr() % 128 != 0 or H.stride(1) != 1:
         with torch.cuda.device(H.device):
             H = pad_rows(H, _pad_buffer(H.size(0), padded_width(F), H.device))
-    spmm_plan(A, H, Z, 1.0, 1.0)
+    spmm_plan(A, H, Z, 1.0, 1.0, c_is_zero=z_is_zero)

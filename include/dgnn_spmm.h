@@ -171,6 +171,17 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
                        int32_t F, float alpha, float beta, void* stream);
 
 /*
+ * The same with beta = 1 for a C the caller knows to hold zeros (just memset, as the `z_loc = zeros` of
+ * gcn.py:18 before its first stage): C = alpha * A * B, and the first stage kernel does not read C -- one
+ * pass over C less, which is a tenth of the traffic on graphs with a few nonzeros per row. Same bits as
+ * dgnn_spmm_plan_f32(beta = 1) on that C. (dgnn_spmm_plan_f32 with beta = 0 zero-fills and then does the same.)
+ */
+int dgnn_spmm_plan_zeroed_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
+                              int32_t n, int32_t m, const float* B, int64_t ldb,
+                              float* C, int64_t ldc, float* partial, int64_t ldp,
+                              int32_t F, float alpha, void* stream);
+
+/*
  * spmm_cusparse's operand list (row-sorted COO, spmm.cpp:16-17) on the fast kernel, for callers that hand
  * over a fresh COO every call as the reference's models do (gcn.py:11) and so cannot keep a plan: a
  * work plan is built on the stream, on the device (column-block stages; per stage the runs grouped by

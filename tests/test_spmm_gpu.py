@@ -209,6 +209,38 @@ def test_plan_path_matches_oracle(n, m, nnz, hubs, F, nstage, piece, alpha, beta
         assert np.array_equal(got[mask], want[mask])
 
 
+@pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece', [c[:7] for c in PLAN_CASES[:6] + PLAN_CASES[13:16]])
+def test_zero_filled_output_variant_gives_the_same_bits(n, m, nnz, hubs, F, nstage, piece):
+    """dgnn_spmm_plan_zeroed_f32 (the first stage does not read C) against dgnn_spmm_plan_f32(beta = 1) on a
+    zero-filled C -- contiguous and as a view of a padded buffer -- and through the aggregate helper."""
+    import spmm_cpp
+    rng = np.random.default_rng(5 * n + F)
+    row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
+    row[row == 3] = 4                                 # an empty row, and rows with nothing in the first column block
+    order = np.lexsort((col, row)); row, col, val = row[order], col[order], val[order]
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    plan = spmm_cpp.SegPlan(blk, nstage, piece)
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(rng.standard_normal((m, F), dtype=np.float32)).to(dev))
+    want = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_plan(blk, Bp, want, 1.0, 1.0, plan)
+    got = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_plan(blk, Bp, got, 1.0, 1.0, plan, c_is_zero=True)
+    assert torch.equal(got, want)
+    wide = torch.zeros(n, spmm_cpp.padded_width(F) + 32, device=dev)
+    spmm_cpp.spmm_plan(blk, Bp, wide[:, :F], 1.0, 1.0, plan, c_is_zero=True)
+    assert torch.equal(wide[:, :F], want) and (wide[:, spmm_cpp.padded_width(F):] == 0).all()
+    H = Bp[:, :F]
+    z = torch.zeros(n, F, device=dev)
+    spmm_cpp.aggregate(blk, H, z, z_is_zero=True)
+    z2 = torch.zeros(n, F, device=dev)
+    spmm_cpp.aggregate(blk, H, z2)
+    assert torch.equal(z, z2)
+    spmm_cpp.aggregate(blk, H, z)                     # second stage: accumulates
+    spmm_cpp.aggregate(blk, H, z2, z_is_zero=False)
+    assert torch.equal(z, z2) and not torch.equal(z, want)
+
+
 def test_plan_is_deterministic_and_covers_every_nonzero():
     import spmm_cpp
     rng = np.random.default_rng(3)

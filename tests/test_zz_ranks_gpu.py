@@ -29,6 +29,9 @@ def _bench(nranks, steps, form='auto', extra=()):
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks),
                '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + common + ['--backend', 'gloo']
     env = dict(os.environ, DGNN_PIPELINE=form, DGNN_FAULT_TIMEOUT='100')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):      # earlier tests of this process set these
+        env.pop(k, None)
+    env['MASTER_PORT'] = str(_free_port())                             # (its own group still holds the old port)
     run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
     assert run.returncode == 0, run.stderr[-3000:]
     line = [l for l in run.stdout.splitlines() if l.startswith('{')][-1]

@@ -55,3 +55,30 @@ def test_loss_after_an_update_matches_1_rank(one_rank, nranks, form):
     different association per rank count, amplified by Adam's normalisation: 1e-4 relative."""
     out = _bench(nranks, 2, form)
     assert abs(out['final_loss_all_ranks'] - one_rank[2]) <= 1e-4 * abs(one_rank[2])
+
+
+def test_weight_gradients_match_1_rank(tmp_path):
+    """The all-reduced weight gradients of the first backward pass at 3 ranks against 1 rank (tools/grad_check.py,
+    same objective at every N: mean over all training nodes): fp32 rounding only, 2e-6 of the largest entry."""
+    import torch
+    outs = {}
+    for n in (1, 3):
+        outs[n] = str(tmp_path / f'grads_n{n}.pt')
+        tail = ['tools/grad_check.py', '--workload', 'cora', '--out', outs[n]]
+        if n == 1:
+            cmd = [sys.executable] + tail
+        else:
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+                   '127.0.0.1', '--master-port', str(_free_port())] + tail + ['--gpus', str(n), '--backend', 'gloo']
+        env = dict(os.environ, DGNN_PIPELINE='auto')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+            env.pop(k, None)
+        env['MASTER_PORT'] = str(_free_port())
+        run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
+        assert run.returncode == 0, run.stderr[-3000:]
+    a, b = (torch.load(outs[n], weights_only=True) for n in (1, 3))
+    assert abs(a['loss'] - b['loss']) <= 1e-6 * abs(a['loss'])
+    for k in ('weight1', 'weight2'):
+        ga, gb = a[k].double(), b[k].double()
+        assert ga.abs().max() > 0
+        assert (ga - gb).abs().max() <= 2e-6 * ga.abs().max(), k

@@ -79,9 +79,10 @@ class NeededRows:
                 self.blocks.append(A)
                 continue
             cols, inv = torch.unique(idx[1], sorted=True, return_inverse=True)
-            blk = torch.sparse_coo_tensor(torch.stack([idx[0], inv]), A.values(), (A.size(0), max(int(cols.numel()), 1)))
+            blk = torch.sparse_coo_tensor(torch.stack([idx[0], inv]), A.values(), (A.size(0), max(int(cols.numel()), 1)),
+                                          is_coalesced=True)   # still sorted by (row, column), no duplicates
             self.cols.append(cols)
-            self.blocks.append(blk._coalesced_(True))       # still sorted by (row, column), no duplicates
+            self.blocks.append(blk)
         counts = torch.tensor([c.numel() for c in self.cols], dtype=torch.long, device=dev)
         every = [torch.empty_like(counts) for _ in range(P)]
         dist.all_gather(every, counts, group=group)

@@ -146,7 +146,7 @@ def test_needed_rows_block_equals_whole_block(env, F):
     gcn.spmm(A, H, want)
     cols, inv = torch.unique(A.indices()[1], sorted=True, return_inverse=True)
     assert cols.numel() < 0.4 * m
-    compact = torch.sparse_coo_tensor(torch.stack([A.indices()[0], inv]), A.values(), (n, cols.numel()))._coalesced_(True)
+    compact = torch.sparse_coo_tensor(torch.stack([A.indices()[0], inv]), A.values(), (n, cols.numel()), is_coalesced=True)
     packed = spmm_cpp.gather_rows(H, cols.to(torch.int32))
     got = torch.zeros(n, F, device=dev)
     gcn.spmm(compact, packed[:, :F], got)

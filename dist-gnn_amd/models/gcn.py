@@ -169,6 +169,7 @@ class StagePipeline:
                       plain list fall back to the P per-block SpMMs).
     mode 'agpipe'     the all-gather cut into two column slabs: slab 2 travels while slab 1 is multiplied
                       (collective bandwidth and overlap; needs at least 64 feature columns).
+                      'agpipe4': four slabs (more overlap, narrower SpMMs; a candidate from 256 columns up).
     mode 'needed'     point-to-point: the owner of stage j sends every peer only the rows of H_j
                       that peer's block references (NeededRows), pipelined like 'bcast'.
     mode 'auto'       (default) the first time a (tag, shape) is aggregated, the forms are run
@@ -194,8 +195,8 @@ class StagePipeline:
 
     def __init__(self, mode=None, inflight=None, cache_input=None):
         self.mode = mode or os.environ.get('DGNN_PIPELINE', 'auto')
-        if self.mode not in ('auto', 'bcast', 'allgather', 'agpipe', 'needed'):
-            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather, agpipe or needed')
+        if self.mode not in ('auto', 'bcast', 'allgather', 'agpipe', 'agpipe4', 'needed'):
+            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather, agpipe, agpipe4 or needed')
         self.inflight = max(1, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))   # 1 = no overlap (debugging)
         self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
         self._bufs = {}
@@ -448,6 +449,7 @@ class StagePipeline:
         forms = ['bcast']
         if self._gather_fits(feat, len(stages)):            # the gathered matrix is P times a block: papers-sized
             forms += ['allgather'] + (['agpipe'] if feat.size(1) > 32 else [])   # graphs cannot afford it
+            forms += ['agpipe4'] if feat.size(1) >= 256 else []                   # four slabs of >= 64 columns
         if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.75:
             forms.append('needed')
         moved = (self.rows_moved, self.rows_full)
@@ -461,8 +463,8 @@ class StagePipeline:
                 self._run_bcast(adj_parts, feat, stages, group, z, None, None)
             elif form == 'allgather':
                 self._run_allgather(adj_parts, feat, stages, group, z, None)
-            elif form == 'agpipe':
-                self._run_agpipe(adj_parts, feat, stages, group, z)
+            elif form in ('agpipe', 'agpipe4'):
+                self._run_agpipe(adj_parts, feat, stages, group, z, chunks=4 if form == 'agpipe4' else 2)
             else:
                 self._run_needed(adj_parts, feat, stages, group, z)
             if feat.is_cuda:
@@ -557,8 +559,8 @@ class StagePipeline:
         if form == 'needed' and plain and self._needed_ok(adj_parts, stages, group):
             self._run_needed(adj_parts, feat, stages, group, z)
             keep = None                                     # compact blocks are not kept: nothing to reuse
-        elif form == 'agpipe' and can_gather:
-            self._run_agpipe(adj_parts, feat, stages, group, z)
+        elif form in ('agpipe', 'agpipe4') and can_gather:
+            self._run_agpipe(adj_parts, feat, stages, group, z, chunks=4 if form == 'agpipe4' else 2)
             keep = None
         elif form == 'allgather' and can_gather:
             self._run_allgather(adj_parts, feat, stages, group, z, keep)

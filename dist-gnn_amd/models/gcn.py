@@ -476,7 +476,8 @@ class StagePipeline:
                 once(f)
             # the vote travels as a host tensor under gloo (its CUDA path stages through the host anyway)
             vote_dev = feat.device if dist.get_backend(group) == 'nccl' else 'cpu'
-            t = torch.tensor([once(f) for f in forms], dtype=torch.float64, device=vote_dev)
+            # best of two timed runs per form: one sample is at the mercy of whatever else the node is doing
+            t = torch.tensor([min(once(f), once(f)) for f in forms], dtype=torch.float64, device=vote_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         times = dict(zip(forms, (float(x) for x in t.tolist())))
         form = min(forms, key=lambda f: (times[f], forms.index(f)))

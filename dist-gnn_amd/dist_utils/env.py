@@ -45,9 +45,18 @@ class DistEnv:
         self.init_dist_groups()
         self.logger = DistLogger(self, log_root=log_root, echo=echo)
         self.timer = DistTimer(self)
-        store_path = os.path.join(tempfile.gettempdir(), f'dgnn-torch-dist-{os.environ.get("MASTER_PORT", "0")}')
-        self.store = dist.FileStore(store_path, self.world_size)
+        self._store = None
         DistEnv.env = self
+
+    @property
+    def store(self):
+        """The FileStore of env.py:22, created on first use (nothing on the GCN path touches it, and a file left
+        behind by an earlier job on the same port should not matter to one that never asks for it)."""
+        if self._store is None:
+            path = os.path.join(tempfile.gettempdir(), 'dgnn-torch-dist-%s-%d-%s' % (
+                os.environ.get('MASTER_PORT', '0'), self.world_size, os.environ.get('TORCHELASTIC_RUN_ID', 'x')))
+            self._store = dist.FileStore(path, self.world_size)
+        return self._store
 
     def __repr__(self):
         return '<DistEnv %d/%d %s>' % (self.rank, self.world_size, self.backend)

@@ -241,6 +241,35 @@ def test_zero_filled_output_variant_gives_the_same_bits(n, m, nnz, hubs, F, nsta
     assert torch.equal(z, z2) and not torch.equal(z, want)
 
 
+def test_plan_spmm_can_be_captured_in_a_hip_graph():
+    """The fast-path entry point only launches kernels on the given stream (no allocation, no synchronisation),
+    so a caller may capture it in a HIP graph and replay it on new operand contents."""
+    import spmm_cpp
+    rng = np.random.default_rng(77)
+    n, m, F = 3000, 2500, 256
+    row, col, val = _rand_csr(rng, n, m, 90000, hub_rows=3)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    plan = spmm_cpp.SegPlan(blk, 3, 64)                 # three stages, cut rows: stage kernels + merge kernels
+    assert plan.ncut > 0
+    B = spmm_cpp.pad_rows(torch.rand(m, F, device=dev))
+    C = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_plan(blk, B, C, 1.0, 0.0, plan)       # warm-up: sizes the partial buffer outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        spmm_cpp.spmm_plan(blk, B, C, 1.0, 0.0, plan)
+    for seed in (1, 2):
+        B2 = spmm_cpp.pad_rows(torch.rand(m, F, device=dev, generator=torch.Generator(device=dev).manual_seed(seed)))
+        want = torch.full((n, F), float('nan'), device=dev)
+        spmm_cpp.spmm_plan(blk, B2, want, 1.0, 0.0, plan)
+        B.copy_(B2)
+        C.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(C, want)
+
+
 def test_plan_is_deterministic_and_covers_every_nonzero():
     import spmm_cpp
     rng = np.random.default_rng(3)

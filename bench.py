@@ -14,8 +14,11 @@ Prints ONE JSON line on rank 0. `value` = edges aggregated per second by the who
 runs 2*L SpMM passes over all nnz(A_hat) entries (L forward + L backward aggregations), so
 value = 2*L*nnz*K / t / 1e9. `roofline` is for the dominant kernel (spmm_stage_kernel), timed
 with HIP events on its launch stream inside the library (dgnn_prof_begin/end) during the timed
-steps. `cpu_baseline` is the CPU oracle (the reference's CPU fallback arithmetic restated in C,
-oracle/spmm_ref.c) on a bounded row sample of the same graph, one host thread.
+steps. `cpu_baseline` (N = 1 only) is the CPU oracle (the reference's CPU fallback arithmetic restated in C,
+oracle/spmm_ref.c) over the same SpMMs on the box's host threads, with the reference's fallback itself
+(torch `C.addmm_(A, B)`) timed beside it on a row prefix. Extras on the line: `gpu_ms_per_step` (GPU time under
+the reference's timer keys), `comm` (N > 1), `alt` (N = 1: the opt-in transform-first epoch time, never the
+value), `final_loss_all_ranks` (training loss over all ranks' training nodes: must not depend on N).
 """
 import argparse
 import json

@@ -227,35 +227,31 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int SEG_MAX = 256;   // LDS strip of a 16-lane group, in entries (32-lane groups: 512, 8-lane groups: 128)
 
-// C-side access helpers: VWC floats per access, guarded per element against F.
+// C-side access helpers: a lane owns 4 consecutive floats of a row of C and touches them as VWC-float vectors
+// while they lie inside [0, F); the vector that straddles F (a width that is no multiple of VWC, in a C with
+// a wider leading dimension) goes element by element: nothing at or past column F is read or written.
 template <int VWC>
 __device__ __forceinline__ void c_load(const float* p, int fbase, int F, f32x2& a01, f32x2& a23) {
-  if constexpr (VWC == 4) {
-    if (fbase < F) { const float4 t = *reinterpret_cast<const float4*>(p); a01 = {t.x, t.y}; a23 = {t.z, t.w}; }
-  } else if constexpr (VWC == 2) {
-    if (fbase < F) { const float2 t = *reinterpret_cast<const float2*>(p); a01 = {t.x, t.y}; }
-    if (fbase + 2 < F) { const float2 t = *reinterpret_cast<const float2*>(p + 2); a23 = {t.x, t.y}; }
-  } else {
-    if (fbase < F) a01.x = p[0];
-    if (fbase + 1 < F) a01.y = p[1];
-    if (fbase + 2 < F) a23.x = p[2];
-    if (fbase + 3 < F) a23.y = p[3];
+  if (VWC == 4 && fbase + 4 <= F) {
+    const float4 t = *reinterpret_cast<const float4*>(p); a01 = {t.x, t.y}; a23 = {t.z, t.w};
+    return;
   }
+  if (VWC >= 2 && fbase + 2 <= F) { const float2 t = *reinterpret_cast<const float2*>(p); a01 = {t.x, t.y}; }
+  else { if (fbase < F) a01.x = p[0]; if (fbase + 1 < F) a01.y = p[1]; }
+  if (VWC >= 2 && fbase + 4 <= F) { const float2 t = *reinterpret_cast<const float2*>(p + 2); a23 = {t.x, t.y}; }
+  else { if (fbase + 2 < F) a23.x = p[2]; if (fbase + 3 < F) a23.y = p[3]; }
 }
 
 template <int VWC>
 __device__ __forceinline__ void c_store(float* p, int fbase, int F, f32x2 a01, f32x2 a23) {
-  if constexpr (VWC == 4) {
-    if (fbase < F) *reinterpret_cast<float4*>(p) = make_float4(a01.x, a01.y, a23.x, a23.y);
-  } else if constexpr (VWC == 2) {
-    if (fbase < F) *reinterpret_cast<float2*>(p) = make_float2(a01.x, a01.y);
-    if (fbase + 2 < F) *reinterpret_cast<float2*>(p + 2) = make_float2(a23.x, a23.y);
-  } else {
-    if (fbase < F) p[0] = a01.x;
-    if (fbase + 1 < F) p[1] = a01.y;
-    if (fbase + 2 < F) p[2] = a23.x;
-    if (fbase + 3 < F) p[3] = a23.y;
+  if (VWC == 4 && fbase + 4 <= F) {
+    *reinterpret_cast<float4*>(p) = make_float4(a01.x, a01.y, a23.x, a23.y);
+    return;
   }
+  if (VWC >= 2 && fbase + 2 <= F) *reinterpret_cast<float2*>(p) = make_float2(a01.x, a01.y);
+  else { if (fbase < F) p[0] = a01.x; if (fbase + 1 < F) p[1] = a01.y; }
+  if (VWC >= 2 && fbase + 4 <= F) *reinterpret_cast<float2*>(p + 2) = make_float2(a23.x, a23.y);
+  else { if (fbase + 2 < F) p[2] = a23.x; if (fbase + 3 < F) p[3] = a23.y; }
 }
 
 // One gather round: R entries of the group's LDS strip starting at j -> R rows of B in flight per lane,

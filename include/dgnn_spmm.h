@@ -49,7 +49,8 @@ int dgnn_coo2csr_i32(const int32_t* row, int64_t nnz, int32_t n,
 /*
  * C[n x F] = alpha * A[n x m] * B[m x F] + beta * C        (fp32, row-major, in place)
  *   A in CSR: rowptr[n+1], col[nnz], val[nnz]; columns of a row in ascending order
- *   B: ldb floats between rows (ldb >= F); C: ldc floats between rows (ldc >= F)
+ *   B: ldb floats between rows (ldb >= F); C: ldc floats between rows (ldc >= F); columns F..ldc-1 of C
+ *   are neither read nor written by any entry point
  *   beta == 0 never reads C (C may hold NaN/uninitialised memory).
  * B and C must not overlap. Each output element is accumulated in ascending
  * nonzero order by one lane, with fused multiply-adds: results are

@@ -1,0 +1,77 @@
+"""Randomised parity of every SpMM entry form against the CPU oracle (hypothesis, derandomised so that a run is
+repeatable): shapes down to one row / one column / one float, empty rows, hub rows, any stage count and piece
+length, strided B and C, any alpha and beta. Uncut rows must carry the oracle's bits; cut rows the fp64 bound."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from test_spmm_gpu import _check, _gpu_block, _rand_csr
+
+pytestmark = pytest.mark.gpu
+
+
+@st.composite
+def _cases(draw):
+    n = draw(st.integers(1, 700))
+    m = draw(st.integers(1, 900))
+    density = draw(st.sampled_from([0.0, 0.002, 0.02, 0.2]))
+    F = draw(st.one_of(st.integers(1, 70), st.sampled_from([100, 128, 172, 256, 300, 602])))
+    return dict(n=n, m=m, nnz=int(n * m * density), F=F,
+                hubs=draw(st.integers(0, 2)), nstage=draw(st.integers(1, 7)),
+                piece=draw(st.sampled_from([1, 5, 16, 33, 256, 1000, 100000])),
+                alpha=draw(st.sampled_from([1.0, 1.0, 0.5, -2.0])), beta=draw(st.sampled_from([1.0, 1.0, 0.0, 0.25])),
+                pad_b=draw(st.sampled_from([0, 4, 32])), pad_c=draw(st.sampled_from([0, 1, 2, 4])),
+                builder=draw(st.sampled_from(['torch', 'device'])), seed=draw(st.integers(0, 2 ** 20)))
+
+
+@settings(max_examples=400, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(_cases())
+def test_every_entry_form_matches_the_oracle(c):
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(c['seed'])
+    n, m, F = c['n'], c['m'], c['F']
+    row, col, val = _rand_csr(rng, n, m, c['nnz'], hub_rows=c['hubs'] if m >= 8 else 0)
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if c['beta'] == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), c['alpha'], c['beta'])
+    rowptr = ref_cpu.coo2csr(row, n)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    Bd = torch.from_numpy(B).to(dev)
+
+    def fresh_c():                                     # C as a view of a wider buffer: any leading dimension
+        buf = torch.full((n, F + c['pad_c']), 7.0, device=dev)
+        buf[:, :F] = torch.from_numpy(C0).to(dev)
+        return buf, buf[:, :F]
+
+    # 1. general kernel, CSR operands, B at any pitch
+    Bw = torch.zeros(m, F + c['pad_b'], device=dev)
+    Bw[:, :F] = Bd
+    buf, C = fresh_c()
+    spmm_cpp.spmm_csr(blk, Bw[:, :F], C, c['alpha'], c['beta'])
+    assert np.array_equal(C.cpu().numpy(), want), 'row kernel must carry the oracle chain'
+    assert (buf[:, F:] == 7.0).all()
+
+    # 2. the reference's call (COO, no plan)
+    buf, C = fresh_c()
+    spmm_cpp.spmm_cusparse(torch.from_numpy(row).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
+                           n, m, Bd, C, c['alpha'], c['beta'])
+    _check(C.cpu().numpy(), want, rowptr, col, val, B, np.nan_to_num(C0), c['alpha'], c['beta'])
+    assert (buf[:, F:] == 7.0).all()
+
+    # 3. fast path with a plan (host- or device-built), padded B
+    plan = (spmm_cpp.SegPlan(blk, c['nstage'], c['piece']) if c['builder'] == 'torch'
+            else spmm_cpp.DevicePlan(blk, min(c['nstage'], 16), c['piece'], F))
+    Bp = spmm_cpp.pad_rows(Bd)
+    buf, C = fresh_c()
+    spmm_cpp.spmm_plan(blk, Bp, C, c['alpha'], c['beta'], plan)
+    got = C.cpu().numpy()
+    _check(got, want, rowptr, col, val, B, np.nan_to_num(C0), c['alpha'], c['beta'])
+    assert (buf[:, F:] == 7.0).all(), 'nothing may be written past column F'
+    lens = np.diff(rowptr)
+    whole = lens <= c['piece']                         # rows no plan can have cut
+    assert np.array_equal(got[whole], want[whole])

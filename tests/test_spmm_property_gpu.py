@@ -75,3 +75,64 @@ def test_every_entry_form_matches_the_oracle(c):
     lens = np.diff(rowptr)
     whole = lens <= c['piece']                         # rows no plan can have cut
     assert np.array_equal(got[whole], want[whole])
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(n=st.integers(1, 400), F=st.integers(1, 700), src_pad=st.integers(0, 5), extra=st.sampled_from([0, 4, 32]),
+       k=st.integers(0, 500), off=st.integers(0, 3), seed=st.integers(0, 2 ** 20))
+def test_pad_and_gather_rows_are_exact_copies(n, F, src_pad, extra, k, off, seed):
+    """dgnn_pad_rows_f32 / dgnn_gather_rows_f32 for any source pitch and alignment: the first F columns are the
+    source's bits, columns F..ldd-1 are zero, rows beyond k and anything outside the destination are untouched."""
+    import spmm_cpp
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(seed)
+    flat = torch.rand(n * (F + src_pad) + off, device=dev, generator=g)
+    src = flat[off:].view(n, F + src_pad)[:, :F]            # any pitch, base possibly only 4-byte aligned
+    ldd = spmm_cpp.padded_width(F) + extra
+    dst = torch.full((n + 1, ldd), 9.0, device=dev)
+    out = spmm_cpp.pad_rows(src, dst[:n])
+    assert out.data_ptr() == dst.data_ptr()
+    assert torch.equal(dst[:n, :F], src) and (dst[:n, F:] == 0).all() and (dst[n] == 9.0).all()
+    idx = torch.randint(0, n, (k,), device=dev, generator=g).int()
+    dst2 = torch.full((k + 1, ldd), 9.0, device=dev)
+    spmm_cpp.gather_rows(src, idx, dst2[:k] if k else dst2[:0])
+    assert torch.equal(dst2[:k, :F], src[idx.long()]) and (dst2[:k, F:] == 0).all() and (dst2[k] == 9.0).all()
+
+
+@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(n=st.integers(1, 3000), m=st.integers(1, 3000), density=st.sampled_from([0.0, 0.001, 0.01, 0.1]),
+       hubs=st.integers(0, 3), nstage=st.integers(1, 16), piece=st.sampled_from([1, 7, 64, 500, 4096]),
+       seed=st.integers(0, 2 ** 20))
+def test_device_built_plan_covers_every_nonzero_once(n, m, density, hubs, nstage, piece, seed):
+    """dgnn_plan_build: the live segments tile the nonzeros exactly once, stay inside one column block and one
+    row, respect the piece length; cut lists and partial-row numbering are consistent; counters match."""
+    import spmm_cpp
+    rng = np.random.default_rng(seed)
+    row, col, val = _rand_csr(rng, n, m, int(n * m * density), hub_rows=hubs if m >= 8 else 0)
+    blk = _gpu_block(row, col, val, n, m)
+    plan = spmm_cpp.DevicePlan(blk, nstage, piece, 64)
+    nseg, ncut, npart = plan.counts()
+    if blk.nnz == 0:
+        assert (nseg, ncut, npart) == (0, 0, 0)
+        return
+    lay = plan.layout
+    ws = plan.ws.cpu().numpy()
+    seg = ws[lay.hdr_ints:lay.hdr_ints + 4 * lay.nstage * lay.nseg_max].reshape(lay.nstage, lay.nseg_max, 4)
+    cut = ws[lay.hdr_ints + 4 * lay.nstage * lay.nseg_max:][:4 * lay.nstage * lay.ncut_max].reshape(lay.nstage, lay.ncut_max, 4)
+    cbw = max(1, -(-m // lay.nstage))
+    covered = np.zeros(blk.nnz, dtype=np.int32)
+    live_total, pieces_seen = 0, {}
+    for st_ in range(lay.nstage):
+        live = seg[st_][seg[st_][:, 0] >= 0]
+        live_total += len(live)
+        for r, k0, k1, out in live:
+            assert 0 < k1 - k0 <= lay.piece and (row[k0:k1] == r).all()
+            assert (np.minimum(col[k0:k1] // cbw, lay.nstage - 1) == st_).all()
+            covered[k0:k1] += 1
+            if out >= 0:
+                pieces_seen[out] = pieces_seen.get(out, 0) + 1
+        for r, pbase, cnt, _ in cut[st_][cut[st_][:, 2] > 0]:
+            assert all(pieces_seen.get(p, 0) == 1 for p in range(pbase, pbase + cnt))
+    assert (covered == 1).all() and live_total == nseg
+    assert sum(pieces_seen.values()) == npart == len(pieces_seen) and npart <= lay.npartial_max
+    assert ncut == int((cut[:, :, 2] > 0).sum())

@@ -241,6 +241,27 @@ def test_zero_filled_output_variant_gives_the_same_bits(n, m, nnz, hubs, F, nsta
     assert torch.equal(z, z2) and not torch.equal(z, want)
 
 
+def test_older_extension_name_and_signatures():
+    """`from sparse_coo_tensor_cpp import sparse_coo_tensor_gpu, spmm_gpu` (1D_CAGNET/dist_1d.py:11): alpha = beta = 1
+    product in place, and the unchecked sparse constructor."""
+    from sparse_coo_tensor_cpp import sparse_coo_tensor_gpu, spmm_gpu
+    from oracle import ref_cpu
+    rng = np.random.default_rng(31)
+    n, m, F = 400, 350, 48
+    row, col, val = _rand_csr(rng, n, m, 9000)
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), 1.0, 1.0)
+    dev = torch.device('cuda:0')
+    idx = torch.from_numpy(np.stack([row, col]).astype(np.int64)).to(dev)
+    A = sparse_coo_tensor_gpu(idx, torch.from_numpy(val).to(dev), (n, m))
+    assert A.is_sparse and tuple(A.shape) == (n, m) and torch.equal(A._indices(), idx)
+    C = torch.from_numpy(C0).to(dev)
+    spmm_gpu(A._indices()[0].int(), A._indices()[1].int(), A._values(), n, m, torch.from_numpy(B).to(dev), C)
+    assert np.array_equal(C.cpu().numpy(), want)
+    assert sparse_coo_tensor_gpu(idx[:, :1], torch.tensor(2.0, device=dev), (n, m))._values().shape == (1,)
+
+
 def test_plan_spmm_can_be_captured_in_a_hip_graph():
     """The fast-path entry point only launches kernels on the given stream (no allocation, no synchronisation),
     so a caller may capture it in a HIP graph and replay it on new operand contents."""

@@ -323,7 +323,7 @@ def main():
                        "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),
                        "scale": args.scale},
             "roofline": roofline, "cpu_baseline": cpu, "gpu_ms_per_step": breakdown, "comm": comm, "alt": alt,
-            "final_loss": round(loss_val, 4), "final_loss_all_ranks": round(global_loss, 6), "setup_s": round(t_build, 1),
+            "peak_device_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "final_loss": round(loss_val, 4), "final_loss_all_ranks": round(global_loss, 6), "setup_s": round(t_build, 1),
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

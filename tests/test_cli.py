@@ -1,0 +1,53 @@
+"""The reference's command-line workflow (prepare_data.py -> main.py, evaluate_dist_env.py), run as a user would,
+on the CPU: data preparation and the micro-benchmark work; training fails LOUDLY because the SpMM has no CPU path
+(the reference would silently fall back to addmm_, gcn.py:13)."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'dist-gnn_amd')
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(args, tmp, timeout=240):
+    env = dict(os.environ, DGNN_DATA_DIR=os.path.join(tmp, 'data'), DGNN_LOG_DIR=os.path.join(tmp, 'logs'),
+               CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    return subprocess.run([sys.executable] + args, cwd=PKG, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_prepare_data_then_training_without_a_gpu_fails_loudly(tmp_path):
+    tmp = str(tmp_path)
+    r = _run(['prepare_data.py', '--dataset', 'cora', '--parts', '1', '2', '--transpose'], tmp)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = sorted(os.listdir(os.path.join(tmp, 'data')))
+    assert files == ['cora_GCN_1_parts', 'cora_GCN_2_parts', 'cora_GCN_full.coo_graph'], files
+    assert len(os.listdir(os.path.join(tmp, 'data', 'cora_GCN_2_parts'))) == 2
+    assert '<COO Graph: cora' in r.stdout and '<Local: 0, |V|: 1354' in r.stdout
+    r = _run(['main.py', '--nprocs', '2', '--backend', 'gloo', '--dataset', 'cora', '--epoch', '2',
+              '--port', str(_free_port())], tmp)
+    assert r.returncode != 0
+    assert 'no CPU path' in r.stderr or 'no CPU path' in r.stdout, r.stderr[-2000:]
+
+
+def test_broadcast_micro_benchmark_runs_on_gloo(tmp_path):
+    tmp = str(tmp_path)
+    cmd = ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'evaluate_dist_env.py', '--backend', 'gloo', '--max-mb', '1']
+    r = _run(cmd, tmp)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = r.stdout + r.stderr
+    for name in os.listdir(os.path.join(tmp, 'logs')) if os.path.isdir(os.path.join(tmp, 'logs')) else []:
+        path = os.path.join(tmp, 'logs', name)
+        for root, _, fs in os.walk(path) if os.path.isdir(path) else [(os.path.dirname(path), [], [name])]:
+            for f in fs:
+                log += open(os.path.join(root, f)).read()
+    assert 'all_gather' in log and '4096 B' in log, log[-1500:]

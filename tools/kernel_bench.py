@@ -16,12 +16,18 @@ import spmm_cpp  # noqa: E402
 from coo_graph import synthetic, graph_utils  # noqa: E402
 
 
-def build_graph(shape, scale, seed, dev):
+def build_graph(shape, scale, seed, dev, reorder=None):
     n, e, f, c, _ = synthetic.SHAPES[shape]
     n, e = int(n * scale), int(e * scale * scale) if scale < 1 else e
     t0 = time.time()
     d = synthetic.make_dataset(shape, seed=seed, device=dev, num_nodes=n, num_edges=e, with_features=False)
-    adj = graph_utils.sym_normalization(d['edge_index'], n)
+    ei = d['edge_index']
+    if reorder == 'degree':          # what a degree-sorted relabelling of the nodes at data-preparation time would give
+        deg = torch.bincount(ei[0], minlength=n) + torch.bincount(ei[1], minlength=n)
+        new_id = torch.empty(n, dtype=torch.long, device=dev)
+        new_id[torch.argsort(deg, descending=True, stable=True)] = torch.arange(n, device=dev)
+        ei = new_id[ei]
+    adj = graph_utils.sym_normalization(ei, n)
     del d
     A = spmm_cpp.CsrBlock.from_coo(adj)
     torch.cuda.synchronize()
@@ -56,9 +62,10 @@ def main():
     ap.add_argument('--builder', default='torch', choices=['torch', 'device'], help='who builds the work plans')
     ap.add_argument('--drop-in', action='store_true', help='also time the reference-signature call spmm_cusparse(row, col, val, ...)')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
+    ap.add_argument('--reorder', default=None, choices=['degree'], help='relabel the nodes by descending degree first')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
-    A, adj = build_graph(args.shape, args.scale, 0, dev)
+    A, adj = build_graph(args.shape, args.scale, 0, dev, args.reorder)
     deg = (A.rowptr[1:] - A.rowptr[:-1]).float()
     print(f'# degree: mean {deg.mean().item():.1f} max {int(deg.max().item())} p99 {deg.quantile(0.99).item():.0f}', flush=True)
     sd, _ = torch.sort(deg, descending=True)

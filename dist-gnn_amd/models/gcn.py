@@ -93,6 +93,7 @@ class NeededRows:
         got = torch.empty(sum(out_split), dtype=torch.int32, device=dev)
         dist.all_to_all_single(got, want, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
         self.send_idx = list(got.split(out_split))
+        self.send_idx_all = got                             # the same lists back to back, in rank order
         self.block_rows = adj_parts[0].size(1)
         # the same number on every rank (K is): ranks must agree on whether this form is worth trying
         self.fraction = float(self.K.sum()) / max(1, P * (P - 1) * self.block_rows)
@@ -172,6 +173,8 @@ class StagePipeline:
                       'agpipe4': four slabs (more overlap, narrower SpMMs; a candidate from 256 columns up).
     mode 'needed'     point-to-point: the owner of stage j sends every peer only the rows of H_j
                       that peer's block references (NeededRows), pipelined like 'bcast'.
+    mode 'needed_a2a' the same rows in ONE all-to-all (all links at once), then the P compact-block SpMMs;
+                      'needed_a2a2': in two column slabs, slab 2 travelling while slab 1 is multiplied.
     mode 'auto'       (default) the first time a (tag, shape) is aggregated, the forms are run
                       and timed on the spot ('needed' joins when under 3/4 of the rows are
                       needed), the slowest rank's time decides (all-reduce MAX, so every rank
@@ -195,8 +198,9 @@ class StagePipeline:
 
     def __init__(self, mode=None, inflight=None, cache_input=None):
         self.mode = mode or os.environ.get('DGNN_PIPELINE', 'auto')
-        if self.mode not in ('auto', 'bcast', 'allgather', 'agpipe', 'agpipe4', 'needed'):
-            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather, agpipe, agpipe4 or needed')
+        if self.mode not in ('auto', 'bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2'):
+            raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather, agpipe, agpipe4, needed, '
+                             'needed_a2a or needed_a2a2')
         self.inflight = max(1, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))   # 1 = no overlap (debugging)
         self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
         self._bufs = {}
@@ -437,6 +441,59 @@ class StagePipeline:
             w.wait()
         return z
 
+    def _run_needed_a2a(self, adj_parts, feat, stages, group, z, chunks=1):
+        """The needed rows of every peer in ONE all-to-all (every xGMI link busy at once; the staged
+        point-to-point form above keeps only the stage owner's links busy), then the P block SpMMs on the
+        compact blocks. ``chunks`` = 2 cuts the feature columns into two slabs (at a multiple of 32 floats):
+        slab 2 travels while slab 1 is multiplied. Same accumulation order as every other form."""
+        env = DistEnv.env
+        rank, timer = env.rank, env.timer
+        nr = NeededRows.of(adj_parts, group)
+        P, F = len(stages), feat.size(1)
+        K = nr.K
+        in_rows = [int(K[rank][src]) for src in range(P)]        # what arrives from src
+        out_rows = [int(K[dst][rank]) for dst in range(P)]       # what goes to dst
+        on_gpu = feat.is_cuda and _gather_override is None
+        step = (-(-F // chunks) + 31) // 32 * 32 if chunks > 1 else F
+        bounds = [(c0, min(c0 + step, F)) for c0 in range(0, F, step)]
+        pending = {}
+
+        def post(c):
+            c0, c1 = bounds[c]
+            w = c1 - c0
+            ld = (w + 31) // 32 * 32 if on_gpu else w
+            send = self._buffers((max(1, sum(out_rows)), ld), feat, 1, f'a2a-send{c}')[0][:sum(out_rows)]
+            recv = self._buffers((max(1, sum(in_rows)), ld), feat, 1, f'a2a-recv{c}')[0][:sum(in_rows)]
+            if sum(out_rows):
+                _gather_rows(feat[:, c0:c1] if w != F else feat, nr.send_idx_all, send)
+            work = dist.all_to_all_single(recv, send, output_split_sizes=in_rows, input_split_sizes=out_rows,
+                                          group=group, async_op=True)
+            pending[c] = (work, recv, w, ld)
+
+        post(0)
+        for c, (c0, c1) in enumerate(bounds):
+            if c + 1 < len(bounds):
+                post(c + 1)
+            work, recv, w, ld = pending.pop(c)
+            with timer.timing_cuda('broadcast'):
+                work.wait()
+            zc = z[:, c0:c1] if w != F else z
+            at = 0
+            with timer.timing_cuda('spmm'):
+                for i, (src, blk) in enumerate(stages):
+                    if src == rank:
+                        spmm(adj_parts[blk], feat[:, c0:c1] if w != F else feat, zc, fresh=(i == 0))
+                        continue
+                    k = in_rows[src]
+                    if k:
+                        rows = recv[at:at + k]
+                        spmm(nr.blocks[src], rows[:, :w] if ld != w else rows, zc, fresh=(i == 0))
+                        at += k
+        self.transfers += P
+        self.rows_moved += sum(in_rows)
+        self.rows_full += nr.block_rows * (P - 1)
+        return z
+
     def _pick_form(self, adj_parts, feat, stages, group, tag):
         """'auto': time both forms once for this (tag, shape) and keep the faster one."""
         key = (tag, feat.size(0), feat.size(1), len(stages))
@@ -451,7 +508,7 @@ class StagePipeline:
             forms += ['allgather'] + (['agpipe'] if feat.size(1) > 32 else [])   # graphs cannot afford it
             forms += ['agpipe4'] if feat.size(1) >= 256 else []                   # four slabs of >= 64 columns
         if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.75:
-            forms.append('needed')
+            forms += ['needed', 'needed_a2a'] + (['needed_a2a2'] if feat.size(1) >= 64 else [])
         moved = (self.rows_moved, self.rows_full)
 
         def once(form):
@@ -465,6 +522,8 @@ class StagePipeline:
                 self._run_allgather(adj_parts, feat, stages, group, z, None)
             elif form in ('agpipe', 'agpipe4'):
                 self._run_agpipe(adj_parts, feat, stages, group, z, chunks=4 if form == 'agpipe4' else 2)
+            elif form in ('needed_a2a', 'needed_a2a2'):
+                self._run_needed_a2a(adj_parts, feat, stages, group, z, chunks=2 if form == 'needed_a2a2' else 1)
             else:
                 self._run_needed(adj_parts, feat, stages, group, z)
             if feat.is_cuda:
@@ -560,6 +619,9 @@ class StagePipeline:
         if form == 'needed' and plain and self._needed_ok(adj_parts, stages, group):
             self._run_needed(adj_parts, feat, stages, group, z)
             keep = None                                     # compact blocks are not kept: nothing to reuse
+        elif form in ('needed_a2a', 'needed_a2a2') and plain and self._needed_ok(adj_parts, stages, group):
+            self._run_needed_a2a(adj_parts, feat, stages, group, z, chunks=2 if form == 'needed_a2a2' else 1)
+            keep = None
         elif form in ('agpipe', 'agpipe4') and can_gather:
             self._run_agpipe(adj_parts, feat, stages, group, z, chunks=4 if form == 'agpipe4' else 2)
             keep = None

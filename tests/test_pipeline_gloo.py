@@ -118,7 +118,7 @@ def _run(world, name, mode='bcast', inflight=2, tmp='/tmp'):
     (2, 'directed', 'bcast', 2), (2, 'multilabel', 'bcast', 2), (1, 'tiny', 'bcast', 2),
     (2, 'tiny', 'auto', 2), (3, 'ragged', 'auto', 2), (2, 'tiny', 'needed', 2), (3, 'ragged', 'needed', 3),
     (2, 'tiny', 'agpipe', 2), (3, 'ragged', 'agpipe', 2), (2, 'ragged', 'agpipe4', 2),
-    (2, 'directed', 'needed', 2)])
+    (2, 'directed', 'needed', 2), (2, 'tiny', 'needed_a2a', 2), (3, 'ragged', 'needed_a2a2', 2), (2, 'directed', 'needed_a2a', 2)])
 def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
     out = _run(world, name, mode, inflight, str(tmp_path))
     for r, res in out.items():
@@ -126,11 +126,11 @@ def test_pipeline_matches_reference(world, name, mode, inflight, tmp_path):
         assert res['out_err'] <= 1e-5 and res['gf_err'] <= 1e-5 and res['gw_err'] <= 1e-5, res
         assert res['cached_err'] <= 1e-6, res
         assert 'spmm' in res['summary'] and 'broadcast' in res['summary'] or world == 1
-        if mode == 'needed' and world > 1:
+        if mode.startswith('needed') and world > 1:
             assert 0 < res['rows'][0] <= res['rows'][1], res['rows']
         if mode == 'auto':       # every rank settled on the same form for every (tag, shape) it tuned
             assert res['choices'] and res['choices'] == out[0]['choices'], (res['choices'], out[0]['choices'])
-            assert set(res['choices'].values()) <= {'bcast', 'allgather', 'agpipe', 'agpipe4', 'needed'} and res['pipeline'].startswith('auto(')
+            assert set(res['choices'].values()) <= {'bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2'} and res['pipeline'].startswith('auto(')
     if out[0].get('gold_losses'):
         got, want = np.array(out[0]['losses']), np.array(out[0]['gold_losses'])
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=6e-5)      # reference logs 4 decimals
@@ -216,7 +216,7 @@ def _eight_worker(rank, world, port, log_dir, q):
         full = coo_graph.COO_Graph('odd', attr_dict=_odd_graph())
         g = coo_graph.Parted_COO_Graph('odd', rank, world, attr_dict=full.partition(world, save=False)[rank])
         res = {'rows': g.local_num_nodes}
-        for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'auto'):
+        for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2', 'auto'):
             gcn._pipeline = gcn.StagePipeline(mode=mode, inflight=3, cache_input=False)
             res[mode] = gcn.broadcast(g.adj_parts, g.features, 'ForwardL1').numpy()
         gcn._pipeline = gcn.StagePipeline(mode='auto')
@@ -267,7 +267,7 @@ def test_eight_ranks_every_form_equals_the_unpartitioned_product(tmp_path):
         assert 'error' not in res, res.get('error')
     s = out[0]['rows']
     assert s == 26
-    for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'auto'):
+    for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2', 'auto'):
         z = np.concatenate([out[r][mode] for r in range(world)])
         assert z.shape[0] == s * world and np.array_equal(z[:n], want), mode
         assert not z[n:].any()                                   # padding rows aggregate nothing

@@ -197,7 +197,7 @@ def scenario_needed_rows(env, rank, world, gold_dir):
     g = coo_graph.Parted_COO_Graph('sparse', rank, world, attr_dict=full.partition(world, save=False, with_transpose=True)[rank],
                                    transposed_backward=True)
     res = {}
-    for mode in ('bcast', 'needed', 'auto'):
+    for mode in ('bcast', 'needed', 'needed_a2a', 'auto'):
         gcn._pipeline = gcn.StagePipeline(mode=mode, cache_input=False)
         z = gcn.broadcast(g.adj_parts, g.features, 'ForwardL1')
         X = g.features.clone().requires_grad_(True)
@@ -210,7 +210,7 @@ def scenario_needed_rows(env, rank, world, gold_dir):
     nr = gcn.NeededRows.of(g.adj_parts, env.world_group)
     out = dict(fraction=nr.fraction, rows=res['needed']['rows'], auto_forms=res['auto']['forms'],
                transfers=[res[m]['transfers'] for m in ('bcast', 'needed', 'auto')])
-    for mode in ('needed', 'auto'):
+    for mode in ('needed', 'needed_a2a', 'auto'):
         out[mode] = all(torch.equal(res[mode][k], res['bcast'][k]) for k in ('z', 'dx', 'dw'))
     gcn._pipeline = None
     return out
@@ -306,7 +306,7 @@ def test_needed_rows_transfer_is_bit_identical(tmp_path):
     for r, res in out.items():
         assert res['needed'] and res['auto'], res             # same bits as whole-block broadcasts, fwd and bwd
         assert res['fraction'] < 0.75 and res['rows'][0] < 0.75 * res['rows'][1], res
-        assert res['auto_forms'] == ['allgather', 'bcast', 'needed']       # 7 feature columns: too narrow for agpipe
+        assert res['auto_forms'] == ['allgather', 'bcast', 'needed', 'needed_a2a']   # 7 feature columns: too narrow for the slab forms
         assert res['transfers'][0] == res['transfers'][1] == res['transfers'][2]
 
 

@@ -49,7 +49,7 @@ def test_forward_pass_gives_the_same_loss_on_2_ranks(one_rank):
     assert abs(out['final_loss_all_ranks'] - one_rank[1]) <= 2e-6 * abs(one_rank[1])      # printed to 6 decimals
 
 
-@pytest.mark.parametrize('nranks,form', [(2, 'auto'), (2, 'needed'), (3, 'agpipe'), (2, 'agpipe4'), (3, 'allgather')])
+@pytest.mark.parametrize('nranks,form', [(2, 'auto'), (2, 'needed'), (3, 'needed_a2a'), (2, 'needed_a2a2'), (3, 'agpipe'), (2, 'agpipe4'), (3, 'allgather')])
 def test_loss_after_an_update_matches_1_rank(one_rank, nranks, form):
     """One optimiser step in between: backward aggregation, weight-gradient all-reduce, Adam. fp32 sums in a
     different association per rank count, amplified by Adam's normalisation: 1e-4 relative."""

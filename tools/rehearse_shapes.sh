@@ -21,7 +21,7 @@ run() {   # name nranks env... -- bench args
 }
 P="--workload products --scale 0.1 --steps 2"
 run products_n1 1 -- $P
-for f in auto bcast allgather agpipe needed; do run products_n2_$f 2 DGNN_PIPELINE=$f -- $P; done
+for f in auto bcast allgather agpipe needed needed_a2a needed_a2a2; do run products_n2_$f 2 DGNN_PIPELINE=$f -- $P; done
 run products_n3_auto 3 -- $P
 C="--workload cora --steps 3"
 run cora_n1 1 -- $C

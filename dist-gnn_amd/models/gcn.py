@@ -176,7 +176,7 @@ class StagePipeline:
     mode 'needed_a2a' the same rows in ONE all-to-all (all links at once), then the P compact-block SpMMs;
                       'needed_a2a2': in two column slabs, slab 2 travelling while slab 1 is multiplied.
     mode 'auto'       (default) the first time a (tag, shape) is aggregated, the forms are run
-                      and timed on the spot ('needed*' join when under 9/10 of the rows are
+                      and timed on the spot ('needed' joins when under 3/4 of the rows are
                       needed), the slowest rank's time decides (all-reduce MAX, so every rank
                       picks the same form), and the choice sticks. Costs a few extra aggregations
                       in the first epoch; results do not depend on the choice.
@@ -507,7 +507,7 @@ class StagePipeline:
         if self._gather_fits(feat, len(stages)):            # the gathered matrix is P times a block: papers-sized
             forms += ['allgather'] + (['agpipe'] if feat.size(1) > 32 else [])   # graphs cannot afford it
             forms += ['agpipe4'] if feat.size(1) >= 256 else []                   # four slabs of >= 64 columns
-        if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.9:
+        if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.75:
             forms += ['needed', 'needed_a2a'] + (['needed_a2a2'] if feat.size(1) >= 64 else [])
         moved = (self.rows_moved, self.rows_full)
 

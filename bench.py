@@ -172,9 +172,13 @@ def main():
     if args.model in ('AdaptiveGCN', 'CachedGCN'):
         layers = 2                                   # fixed two-layer models in the reference
 
-    if os.environ.get('DGNN_FAULT_TIMEOUT'):       # debugging aid: dump every thread's stack and exit if stuck
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['DGNN_FAULT_TIMEOUT']), exit=True)
+    # Watchdog: dump every thread's stack and exit if the run is still going after this many seconds (a rank stuck
+    # in a collective would otherwise sit there until the launcher's own limit, saying nothing). Multi-rank runs
+    # get one by default; DGNN_FAULT_TIMEOUT sets or (0) removes it.
+    import faulthandler
+    limit = int(os.environ.get('DGNN_FAULT_TIMEOUT', 1500 if int(os.environ.get('WORLD_SIZE', 1)) > 1 else 0))
+    if limit > 0:
+        faulthandler.dump_traceback_later(limit, exit=True)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     rank = int(os.environ.get('RANK', 0))
@@ -328,6 +332,7 @@ def main():
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == '__main__':

@@ -62,3 +62,18 @@ def test_binding_signatures_match_the_header():
         decl = protos[name].strip()
         count = 0 if decl in ('', 'void') else decl.count(',') + 1
         assert count == len(args), f'{name}: header has {count} arguments, the stub {len(args)}'
+
+
+def test_missing_library_is_a_loud_error_not_an_import_error(tmp_path):
+    """Without libdgnn_spmm.so the stub must raise (RuntimeError, not ImportError: the reference's
+    `try: from spmm_cpp import ...; except ImportError:` at gcn.py:9-13 would otherwise fall back to addmm_ silently)."""
+    import shutil
+    import subprocess
+    import sys
+    pkg = tmp_path / 'pkg'
+    shutil.copytree(os.path.join(ROOT, 'dist-gnn_amd', 'spmm_cpp'), pkg / 'spmm_cpp')      # the stub without lib/
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'try:\n    import spmm_cpp\nexcept ImportError as e:\n    print("IMPORTERROR", e)\n'
+            'except RuntimeError as e:\n    print("RUNTIMEERROR", e)\nelse:\n    print("IMPORTED")\n' % str(pkg))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120).stdout
+    assert out.startswith('RUNTIMEERROR') and 'no CPU fallback' in out, out

@@ -81,25 +81,9 @@ def _gcn_nocache():
     return _N()
 
 
-class AdaptiveGCNLayer(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, features, weight, adj_parts, btype):
-        ctx.save_for_backward(features, weight)
-        ctx.adj_parts, ctx.btype = adj_parts, btype
-        z = adaptive_broadcast(adj_parts, features, btype)
-        with DistEnv.env.timer.timing_cuda('mm'):
-            return torch.mm(z, weight)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        features, weight = ctx.saved_tensors
-        ag = adaptive_broadcast(ctx.adj_parts, grad_output, 'backward_' + ctx.btype)
-        with DistEnv.env.timer.timing_cuda('mm'):
-            grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
-            grad_weight = _gcn.grad_weight_product(features, ag)
-        with DistEnv.env.timer.timing_cuda('all_reduce'):
-            DistEnv.env.all_reduce_sum(grad_weight)
-        return grad_features, grad_weight, None, None
+# the layer of dist_1d.py:145-190: tags are the broadcast types themselves ('layer1', 'backward_layer1', ...)
+AdaptiveGCNLayer = _gcn.aggregation_layer('AdaptiveGCNLayer', adaptive_broadcast, forward_tag=lambda t: t,
+                                          backward_tag=lambda t: 'backward_' + t)
 
 
 class AdaptiveGCN(nn.Module):

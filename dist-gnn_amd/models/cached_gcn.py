@@ -20,7 +20,6 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from dist_utils import DistEnv
 from . import gcn as _gcn
 
 g_cache = defaultdict(dict)
@@ -64,27 +63,8 @@ def cached_broadcast(local_adj_parts, local_feature, tag):
     return _gcn.pipeline().run(local_adj_parts, local_feature, tag, policy=_CachePolicy(tag))
 
 
-class CachedDistGCNLayer(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, features, weight, adj_parts, tag):
-        ctx.save_for_backward(features, weight)
-        ctx.adj_parts, ctx.tag = adj_parts, tag
-        z_local = cached_broadcast(adj_parts, features, 'Forward' + tag)
-        with DistEnv.env.timer.timing_cuda('mm'):
-            return torch.mm(z_local, weight)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        features, weight = ctx.saved_tensors
-        ag = cached_broadcast(ctx.adj_parts, grad_output, 'Backward' + ctx.tag)
-        with DistEnv.env.timer.timing_cuda('mm'):
-            grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
-            grad_weight = _gcn.grad_weight_product(features, ag)
-        with DistEnv.env.timer.timing_cuda('all_reduce'):
-            DistEnv.env.all_reduce_sum(grad_weight)
-        return grad_features, grad_weight, None, None
-
-
+# gcn.py:33-53 around cached_broadcast (cached_gcn.py:59-79)
+CachedDistGCNLayer = _gcn.aggregation_layer('CachedDistGCNLayer', cached_broadcast)
 DistGCNLayer = CachedDistGCNLayer
 
 

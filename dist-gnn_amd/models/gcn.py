@@ -710,6 +710,37 @@ class DistGCNLayer(torch.autograd.Function):
         return grad_features, grad_weight, None, None
 
 
+def aggregation_layer(name, aggregate, forward_tag=lambda t: 'Forward' + t, backward_tag=lambda t: 'Backward' + t,
+                      reduce_grad=None):
+    """The layer of gcn.py:33-53 around another aggregation: ``out = aggregate(adj_parts, H, tag) @ W`` with the
+    same backward formulas (aggregate grad_output with the same blocks, ``ag W^T`` only if the input needs it,
+    ``H^T ag`` summed over the ranks by ``reduce_grad``, default the world all-reduce). The cached, adaptive and
+    1.5D variants are this with their own ``aggregate``."""
+
+    class Layer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, features, weight, adj_parts, tag):
+            ctx.save_for_backward(features, weight)
+            ctx.adj_parts, ctx.tag = adj_parts, tag
+            z_local = aggregate(adj_parts, features, forward_tag(tag))
+            with DistEnv.env.timer.timing_cuda('mm'):
+                return torch.mm(z_local, weight)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            features, weight = ctx.saved_tensors
+            ag = aggregate(ctx.adj_parts, grad_output, backward_tag(ctx.tag))
+            with DistEnv.env.timer.timing_cuda('mm'):
+                grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
+                grad_weight = grad_weight_product(features, ag)
+            with DistEnv.env.timer.timing_cuda('all_reduce'):
+                (reduce_grad or DistEnv.env.all_reduce_sum)(grad_weight)
+            return grad_features, grad_weight, None, None
+
+    Layer.__name__ = Layer.__qualname__ = name
+    return Layer
+
+
 class GCN(nn.Module):
     """ReLU GCN; ``num_layers=3`` is the reference model (gcn.py:56-72): weights drawn with
     torch.rand after torch.manual_seed(0) on the CPU, in layer order, then moved to the device."""

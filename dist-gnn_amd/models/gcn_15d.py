@@ -70,25 +70,10 @@ class _NoCache:
         pass
 
 
-class Dist15DLayer(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, features, weight, adj_parts, tag):
-        ctx.save_for_backward(features, weight)
-        ctx.adj_parts, ctx.tag = adj_parts, tag
-        z = broadcast_15d(adj_parts, features, 'Forward' + tag)
-        with DistEnv.env.timer.timing_cuda('mm'):
-            return torch.mm(z, weight)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        features, weight = ctx.saved_tensors
-        ag = broadcast_15d(ctx.adj_parts, grad_output, 'Backward' + ctx.tag)
-        with DistEnv.env.timer.timing_cuda('mm'):
-            grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
-            grad_weight = _gcn.grad_weight_product(features, ag)
-        with DistEnv.env.timer.timing_cuda('all_reduce'):
-            dist.all_reduce(grad_weight, op=dist.ReduceOp.SUM, group=_rep.col_group)
-        return grad_features, grad_weight, None, None
+# weight gradients are summed over the column group only: its members hold the distinct row blocks
+Dist15DLayer = _gcn.aggregation_layer(
+    'Dist15DLayer', lambda adj_parts, feat, tag: broadcast_15d(adj_parts, feat, tag),
+    reduce_grad=lambda g: dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_rep.col_group))
 
 
 class GCN15D(_gcn.GCN):

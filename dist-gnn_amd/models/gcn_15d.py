@@ -13,10 +13,7 @@ partial sums of the c replicas are then all-reduced over the row group (dist_15d
 grad_weight is all-reduced over the column group only (dist_15d.py:29) because row-group replicas
 hold identical rows.
 """
-import torch
 import torch.distributed as dist
-import torch.nn as nn
-import torch.nn.functional as F
 
 from dist_utils import DistEnv
 from . import gcn as _gcn

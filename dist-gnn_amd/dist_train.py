@@ -9,7 +9,6 @@ import torch
 import torch.nn as nn
 
 from coo_graph import Parted_COO_Graph
-from dist_utils import DistEnv
 from models import GCN, CachedGCN
 
 

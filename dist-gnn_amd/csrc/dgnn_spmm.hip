@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
 
   float* const dst = direct ? (C + (int64_t)s.x * ldc + fbase) : (P + (int64_t)s.w * ldp + fbase);
   f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-  // pieces start from 0, direct runs from C -- unless the caller knows C holds zeros (`fresh`: the first
-  // stage after a zero fill), which saves one read pass over C
+  // pieces start from 0, direct runs from C -- unless C has no value yet (`fresh`: the first stage of a product
+  // that overwrites C), in which case C is not read at all; an empty run (k0 == k1) then stores the row's zeros
   if (live && direct && !fresh) c_load<VWC>(dst, fbase, F, a01, a23);
 
   // A run is walked strip by strip (SEGM entries). Per strip --
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
 template <int VWC>
 __global__ __launch_bounds__(256) void merge_kernel(
     const int4* __restrict__ cut, int32_t ncut, const float* __restrict__ P, int64_t ldp,
-    float* __restrict__ C, int64_t ldc, int32_t F) {
+    float* __restrict__ C, int64_t ldc, int32_t F, int fresh) {
   const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (run >= ncut) return;
   const int4 c4 = cut[run];                    // {row, pbase, count, -}
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void merge_kernel(
   for (int f = lane * 4; f < F; f += 256) {
     float* c = C + (int64_t)c4.x * ldc + f;
     f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-    c_load<VWC>(c, f, F, a01, a23);
+    if (!fresh) c_load<VWC>(c, f, F, a01, a23);            // fresh: the row has no value yet (see the stage kernel)
     const float* p = P + (int64_t)c4.y * ldp + f;
     int s = 0;
     for (; s + 4 <= c4.z; s += 4) {
@@ -551,6 +551,9 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(const int32_t* __restric
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int a = rowptr[i];
     const int k1 = rowptr[i + 1];
+    // a row with nothing in the first column block is listed there as an empty run: the first stage then
+    // stores every row (dgnn_plan.covers_rows)
+    if (a >= k1 || (ns > 1 && col[a] >= cbw)) atomicAdd(&local[0][0], 1);
     for (int st = 0; st < ns && a < k1; ++st) {
       const int b = (st == ns - 1) ? k1 : col_lower_bound(col, a, k1, (st + 1) * cbw);
       const int len = b - a;
@@ -601,7 +604,8 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restric
       const int b = (a >= k1) ? k1 : (st == ns - 1) ? k1 : col_lower_bound(col, a, k1, (st + 1) * cbw);
       lend[st][threadIdx.x] = b;
       const int len = b - a;
-      if (len > 0 && len <= piece) lrank[st][threadIdx.x] = (unsigned short)atomicAdd(&lcnt[st][len_class(len)], 1);
+      if (valid && (len > 0 || st == 0) && len <= piece)
+        lrank[st][threadIdx.x] = (unsigned short)atomicAdd(&lcnt[st][len_class(len)], 1);
       a = b;
     }
     __syncthreads();
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restric
       const int b = lend[st][threadIdx.x];
       const int len = b - a;
       int4* const sseg = seg + st * seg_stride;
-      if (len > 0 && len <= piece) {
+      if (valid && (len > 0 || st == 0) && len <= piece) {      // stage 0 lists empty runs too
         sseg[lbase[st][len_class(len)] + lrank[st][threadIdx.x]] = make_int4((int)i, a, b, -1);
       } else if (len > piece) {
         int* const h = hdr + st * PLAN_HDR_STAGE;
@@ -928,14 +932,14 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
   dgnn_plan plan;
   plan.nstage = d.nstage; plan.seg = plan_ws + d.hdr_ints; plan.stage_seg_off = seg_off;
   plan.cut = plan_ws + d.hdr_ints + 4 * d.nstage * d.nseg_max; plan.stage_cut_off = cut_off;
-  plan.npartial = d.npartial_max; plan.max_seg_len = d.piece;
+  plan.npartial = d.npartial_max; plan.max_seg_len = d.piece; plan.covers_rows = 1;
   return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
 }
 
 static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float* val,
                           int32_t n, int32_t m, const float* B, int64_t ldb,
                           float* C, int64_t ldc, float* partial, int64_t ldp,
-                          int32_t F, float alpha, float beta, bool c_is_zero, void* stream) {
+                          int32_t F, float alpha, float beta, void* stream) {
   if (!plan) return fail(DGNN_E_BADARG, "spmm_plan: null plan%s", "");
   if (n < 0 || m < 0 || F < 0) return fail(DGNN_E_BADARG, "spmm_plan: negative size%s", "");
   if (n == 0 || F == 0) return DGNN_OK;
@@ -943,12 +947,15 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
   hipStream_t s = (hipStream_t)stream;
   // Stages accumulate into C one after another and a row need not appear in stage 0, so C holds
   // beta*C before the first stage.
-  if (beta != 1.f) {
+  const bool empty = plan->nstage <= 0 || !plan->stage_seg_off || plan->stage_seg_off[plan->nstage] == 0;
+  // beta == 0 with a plan whose first stage lists every row: nothing to prepare, C is overwritten
+  const bool overwrite = beta == 0.f && !empty && plan->covers_rows != 0 && plan->stage_seg_off[1] > plan->stage_seg_off[0];
+  if (beta != 1.f && !overwrite) {
     ProfScope prof(s, 1);
     hipLaunchKernelGGL(scale_rows_kernel, dim3(capped_blocks((int64_t)n * F, 8192)), dim3(256), 0, s, C, ldc, n, F, beta);
     DGNN_HIP(hipGetLastError());
   }
-  if (plan->nstage <= 0 || !plan->stage_seg_off || plan->stage_seg_off[plan->nstage] == 0) return DGNN_OK;
+  if (empty) return DGNN_OK;
   if (plan->max_seg_len <= 0)
     return fail(DGNN_E_BADARG, "spmm_plan: plan->max_seg_len must be positive%s (%lld)", "", plan->max_seg_len);
   if (!plan->seg || !plan->stage_cut_off || !col || !val || !B)
@@ -960,7 +967,7 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
   if (ncut > 0 && (!partial || !plan->cut || ldp < ldb || ldp % 4 != 0 || !aligned(partial, 16)))
     return fail(DGNN_E_BADARG, "spmm_plan: cut segments need a 16-byte aligned partial buffer with ldp >= ldb, ldp %% 4 == 0%s", "");
   const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : ((ldc % 2 == 0 && aligned(C, 8)) ? 2 : 1);
-  bool fresh = c_is_zero || beta == 0.f;       // C holds zeros until the first stage kernel has run
+  bool fresh = beta == 0.f;                    // C holds nothing (or zeros) until the first stage and its merge have run
   const bool wide = ((uint64_t)(m > 0 ? m : 1) * (uint64_t)ldb * 4u) >= 0xffffff00ull || g_variant == 2;   // 32-bit row offsets?
   for (int32_t st = 0; st < plan->nstage; ++st) {
     const int64_t s0 = plan->stage_seg_off[st], s1 = plan->stage_seg_off[st + 1];
@@ -995,7 +1002,6 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
 #undef DGNN_LAUNCH
       }
       if (rc != DGNN_OK) return rc;
-      fresh = false;
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
     if (p1 > p0) {
@@ -1003,11 +1009,12 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
       const int32_t nc = (int32_t)(p1 - p0);
       const int4* cutp = reinterpret_cast<const int4*>(plan->cut) + p0;
       const dim3 grid((unsigned)((nc + 3) / 4));
-      if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F);
-      else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F);
-      else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F);
+      if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
+      else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
+      else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
       DGNN_HIP(hipGetLastError());
     }
+    if (s1 > s0 || p1 > p0) fresh = false;
   }
   return DGNN_OK;
 }
@@ -1016,14 +1023,14 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
                        int32_t n, int32_t m, const float* B, int64_t ldb,
                        float* C, int64_t ldc, float* partial, int64_t ldp,
                        int32_t F, float alpha, float beta, void* stream) {
-  return spmm_plan_impl(plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, false, stream);
+  return spmm_plan_impl(plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
 }
 
-int dgnn_spmm_plan_zeroed_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
-                              int32_t n, int32_t m, const float* B, int64_t ldb,
-                              float* C, int64_t ldc, float* partial, int64_t ldp,
-                              int32_t F, float alpha, void* stream) {
-  return spmm_plan_impl(plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, 1.f, true, stream);
+int dgnn_spmm_plan_overwrite_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
+                                 int32_t n, int32_t m, const float* B, int64_t ldb,
+                                 float* C, int64_t ldc, float* partial, int64_t ldp,
+                                 int32_t F, float alpha, void* stream) {
+  return spmm_plan_impl(plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, 0.f, stream);
 }
 
 }  // extern "C"

@@ -149,13 +149,46 @@ def _csr_block(A):
 
 
 def spmm(A, B, C, fresh=False):
-    """C += A @ B in place (alpha = beta = 1, as gcn.py:11 calls spmm_cusparse). ``fresh``: C was zero-filled
-    a moment ago and nothing has been added yet (the first stage of an aggregation): the kernel then
-    skips reading it. Same result either way."""
+    """C += A @ B in place (alpha = beta = 1, as gcn.py:11 calls spmm_cusparse). ``fresh``: nothing has been
+    added to C yet (the first stage of an aggregation) -- C = A @ B, whatever C holds: the HIP path neither
+    zero-fills nor reads it (see _new_output); a test backend gets a zeroed C and adds."""
     if _spmm_override is not None:
+        if fresh:
+            C.zero_()
         return _spmm_override(A, B, C)
     import spmm_cpp
-    spmm_cpp.aggregate(_csr_block(A), B, C, z_is_zero=fresh)
+    spmm_cpp.aggregate(_csr_block(A), B, C, overwrite=fresh)
+
+
+class _Sum:
+    """z = sum of stage products, in the order given: the first product that is actually issued overwrites z
+    (no zero fill, no read-back), the others accumulate; a sum with no term at all is zero."""
+
+    def __init__(self, z):
+        self.z, self.started = z, False
+
+    def add(self, A, B):
+        spmm(A, B, self.z, fresh=not self.started)
+        self.started = True
+
+    def done(self):
+        if not self.started:
+            self.z.zero_()
+        return self.z
+
+
+def _new_output(rows, feat, padded):
+    """The [rows, F] output of an aggregation. On the HIP path it is NOT zero-filled: the first stage product
+    overwrites it (_Sum). ``padded``: a [rows, F] view of a buffer at the kernel's 128-byte row pitch (aligned
+    float4 read-modify-write in the SpMM, aligned leading dimension for the GEMM that consumes it); columns past
+    F are never read or written. DGNN_POISON=1 (tests) fills it with NaN so that any element left unwritten shows."""
+    F = feat.size(1)
+    hip = feat.is_cuda and _spmm_override is None
+    ld = (F + 31) // 32 * 32 if (padded and hip) else F
+    buf = (torch.empty if hip else torch.zeros)((rows, ld), dtype=feat.dtype, device=feat.device)
+    if hip and os.environ.get('DGNN_POISON') == '1':
+        buf.fill_(float('nan'))
+    return buf[:, :F] if ld != F else buf
 
 
 class StagePipeline:
@@ -270,14 +303,15 @@ class StagePipeline:
                 spmm(slab, gathered[:, :F] if ld != F else gathered, z, fresh=True)
             return z
         members = sorted(src for src, _ in stages)
-        for i, (src, blk) in enumerate(stages):
+        acc = _Sum(z)
+        for src, blk in stages:
             pos = members.index(src)
             block = gathered[pos * s:(pos + 1) * s, :F]
             if keep is not None and src != rank:
                 keep[src] = block
             with timer.timing_cuda('spmm'):
-                spmm(adj_parts[blk], block, z, fresh=(i == 0))
-        return z
+                acc.add(adj_parts[blk], block)
+        return acc.done()
 
     def _run_agpipe(self, adj_parts, feat, stages, group, z, chunks=2):
         """All-gather in column chunks: the feature columns are cut into `chunks` slabs (at multiples of 32
@@ -321,9 +355,11 @@ class StagePipeline:
                 if fused:
                     spmm(slab, gathered[:, :w], zc, fresh=True)
                 else:
-                    for i, (src, blk) in enumerate(stages):
+                    acc = _Sum(zc)
+                    for src, blk in stages:
                         pos = members.index(src)
-                        spmm(adj_parts[blk], gathered[pos * s:(pos + 1) * s, :w], zc, fresh=(i == 0))
+                        acc.add(adj_parts[blk], gathered[pos * s:(pos + 1) * s, :w])
+                    acc.done()
         self.transfers += P
         return z
 
@@ -360,6 +396,7 @@ class StagePipeline:
             self.transfers += 1
             pending[i] = (work, buf[:, :F] if ld != F else buf)
 
+        acc = _Sum(z)
         for i in range(min(depth - 1, n)):
             post(i)
         for i, (src, blk) in enumerate(stages):
@@ -376,8 +413,8 @@ class StagePipeline:
             if keep is not None and src != rank:
                 keep[src] = block
             with timer.timing_cuda('spmm', cs):
-                spmm(adj_parts[blk], block, z, fresh=(i == 0))
-        return z
+                acc.add(adj_parts[blk], block)
+        return acc.done()
 
     def _run_needed(self, adj_parts, feat, stages, group, z):
         env = DistEnv.env
@@ -419,6 +456,7 @@ class StagePipeline:
             pending[i] = (dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, src, group)]), buf)
             self.rows_moved += k
 
+        acc = _Sum(z)
         for i in range(min(depth - 1, n)):
             post(i)
         for i, (src, blk) in enumerate(stages):
@@ -431,15 +469,15 @@ class StagePipeline:
             self.transfers += 1
             if src == rank:
                 with timer.timing_cuda('spmm'):
-                    spmm(adj_parts[blk], feat, z, fresh=(i == 0))
+                    acc.add(adj_parts[blk], feat)
                 continue
             self.rows_full += nr.block_rows
             if buf is not None:
                 with timer.timing_cuda('spmm'):
-                    spmm(nr.blocks[src], buf[:, :F] if ld != F else buf, z, fresh=(i == 0))
+                    acc.add(nr.blocks[src], buf[:, :F] if ld != F else buf)
         for w in sends:                       # the send buffer is reused by the next aggregation
             w.wait()
-        return z
+        return acc.done()
 
     def _run_needed_a2a(self, adj_parts, feat, stages, group, z, chunks=1):
         """The needed rows of every peer in ONE all-to-all (every xGMI link busy at once; the staged
@@ -477,18 +515,19 @@ class StagePipeline:
             work, recv, w, ld = pending.pop(c)
             with timer.timing_cuda('broadcast'):
                 work.wait()
-            zc = z[:, c0:c1] if w != F else z
+            acc = _Sum(z[:, c0:c1] if w != F else z)
             at = 0
             with timer.timing_cuda('spmm'):
-                for i, (src, blk) in enumerate(stages):
+                for src, blk in stages:
                     if src == rank:
-                        spmm(adj_parts[blk], feat[:, c0:c1] if w != F else feat, zc, fresh=(i == 0))
+                        acc.add(adj_parts[blk], feat[:, c0:c1] if w != F else feat)
                         continue
                     k = in_rows[src]
                     if k:
                         rows = recv[at:at + k]
-                        spmm(nr.blocks[src], rows[:, :w] if ld != w else rows, zc, fresh=(i == 0))
+                        acc.add(nr.blocks[src], rows[:, :w] if ld != w else rows)
                         at += k
+                acc.done()
         self.transfers += P
         self.rows_moved += sum(in_rows)
         self.rows_full += nr.block_rows * (P - 1)
@@ -512,7 +551,7 @@ class StagePipeline:
         moved = (self.rows_moved, self.rows_full)
 
         def once(form):
-            z = torch.zeros((adj_parts[stages[0][1]].size(0), feat.size(1)), dtype=feat.dtype, device=feat.device)
+            z = _new_output(adj_parts[stages[0][1]].size(0), feat, False)
             if feat.is_cuda:
                 torch.cuda.synchronize(feat.device)
             t0 = time.perf_counter()
@@ -584,12 +623,7 @@ class StagePipeline:
         # saved for backward (a ReLU output). Its bits are never changed here.
         feat = orig.data
         rows = adj_parts[stages[0][1]].size(0) if stages else feat.size(0)
-        if padded_out and feat.is_cuda and _spmm_override is None and feat.size(1) % 32:
-            # rows of z on 128-byte lines: aligned float4 read-modify-write in the SpMM and an aligned
-            # leading dimension for the GEMM that consumes z; the caller sees the [s, F] view
-            z = torch.zeros((rows, (feat.size(1) + 31) // 32 * 32), dtype=feat.dtype, device=feat.device)[:, :feat.size(1)]
-        else:
-            z = torch.zeros((rows, feat.size(1)), dtype=feat.dtype, device=feat.device)
+        z = _new_output(rows, feat, padded_out)
         plain = policy is None
         if plain and len(stages) == 1 and stages[0][0] == rank:
             with timer.timing_cuda('spmm'):
@@ -605,10 +639,11 @@ class StagePipeline:
                     with timer.timing_cuda('spmm'):
                         spmm(adj_parts.slab, hit[1]['gathered'][:, :feat.size(1)], z, fresh=True)
                     return z
-                for i, (src, blk) in enumerate(stages):
+                acc = _Sum(z)
+                for src, blk in stages:
                     with timer.timing_cuda('spmm'):
-                        spmm(adj_parts[blk], feat if src == rank else hit[1][src], z, fresh=(i == 0))
-                return z
+                        acc.add(adj_parts[blk], feat if src == rank else hit[1][src])
+                return acc.done()
         keep = {} if cacheable else None
 
         _trace('run', rank, tag, tuple(feat.shape), self.mode)

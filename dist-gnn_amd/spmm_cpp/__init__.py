@@ -37,7 +37,7 @@ _p, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c
 
 class _CPlan(ctypes.Structure):          # struct dgnn_plan (include/dgnn_spmm.h)
     _fields_ = [('nstage', _i32), ('seg', _p), ('stage_seg_off', _p), ('cut', _p),
-                ('stage_cut_off', _p), ('npartial', _i64), ('max_seg_len', _i32)]
+                ('stage_cut_off', _p), ('npartial', _i64), ('max_seg_len', _i32), ('covers_rows', _i32)]
 
 
 class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn_spmm.h)
@@ -63,7 +63,7 @@ _SIGNATURES = {                          # argument types, in the order of inclu
     'dgnn_plan_layout_for': [_i32, _i32, _i64, _i64, _i32, _i32, ctypes.POINTER(_CLayout)],
     'dgnn_plan_build': [_p, _p, _i32, _i32, ctypes.POINTER(_CLayout), _p, _p],
     'dgnn_spmm_plan_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
-    'dgnn_spmm_plan_zeroed_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
+    'dgnn_spmm_plan_overwrite_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
 }
 for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
@@ -354,6 +354,16 @@ class SegPlan:
             pk1 = torch.minimum(pk0 + piece_len, k1[run_of])
             prow, pcb, pcut = run_row[run_of], run_cb[run_of], is_cut[run_of]
             pout = torch.where(pcut, torch.cumsum(pcut.long(), 0) - 1, torch.full_like(pk0, -1))
+            # rows with nothing in the first column block are listed there as empty runs: the first stage
+            # then stores every row and a product that overwrites C needs no zero fill (covers_rows)
+            has0 = torch.zeros(n, dtype=torch.bool, device=dev)
+            has0[run_row[run_cb == 0]] = True
+            miss = torch.nonzero(~has0).flatten()
+            if miss.numel():
+                at = rp[miss]
+                prow, pk0, pk1 = torch.cat([prow, miss]), torch.cat([pk0, at]), torch.cat([pk1, at])
+                pcb = torch.cat([pcb, torch.zeros_like(miss)])
+                pout = torch.cat([pout, torch.full_like(miss, -1)])
             order = torch.argsort(pcb * (piece_len + 1) + (piece_len - (pk1 - pk0)), stable=True)
             self.seg = torch.stack([prow, pk0, pk1, pout], dim=1)[order].int().contiguous()
             self.stage_seg_off = torch.cat([torch.zeros(1, **i64), torch.cumsum(torch.bincount(pcb, minlength=nstage), 0)]).cpu().contiguous()
@@ -368,7 +378,7 @@ class SegPlan:
         self.nseg = self.seg.size(0)
         self.ncut = self.cut.size(0)
         self.c = _CPlan(nstage, self.seg.data_ptr(), self.stage_seg_off.data_ptr(), self.cut.data_ptr(),
-                        self.stage_cut_off.data_ptr(), self.npartial, int(piece_len))
+                        self.stage_cut_off.data_ptr(), self.npartial, int(piece_len), 1 if nnz else 0)
         self._partial = None
 
     def partial(self, ldb, dev):
@@ -396,7 +406,7 @@ class DevicePlan:
             self.stage_cut_off = torch.zeros(lay.nstage + 1, dtype=torch.long)
             self.npartial = self.nseg = self.ncut = 0
             self.c = _CPlan(lay.nstage, self.ws.data_ptr(), self.stage_seg_off.data_ptr(), self.ws.data_ptr(),
-                            self.stage_cut_off.data_ptr(), 0, lay.piece)
+                            self.stage_cut_off.data_ptr(), 0, lay.piece, 0)
             self._partial = None
             return
         self.ws = torch.empty(lay.ws_ints, dtype=torch.int32, device=A.device)
@@ -411,7 +421,7 @@ class DevicePlan:
         base = self.ws.data_ptr()
         self.c = _CPlan(lay.nstage, base + 4 * lay.hdr_ints, self.stage_seg_off.data_ptr(),
                         base + 4 * (lay.hdr_ints + 4 * lay.nstage * lay.nseg_max), self.stage_cut_off.data_ptr(),
-                        self.npartial, lay.piece)
+                        self.npartial, lay.piece, 1)
         self._partial = None
 
     def counts(self):
@@ -443,10 +453,10 @@ def _plan_for(A, F):
     return plans[ns]
 
 
-def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, c_is_zero=False):
+def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
     """C <- alpha * A @ B[:, :F] + beta * C, fast path. ``B`` is a padded feature block from
     ``pad_rows`` (16-byte aligned rows); ``C`` is any row-major [n, F] fp32 matrix.
-    ``c_is_zero`` (with beta = 1): the caller has just zero-filled C, so the kernel need not read it."""
+    ``overwrite``: C <- alpha * A @ B whatever C holds (it may be uninitialised); beta is ignored."""
     bptr, ldb = _dense(B, 'B')
     cptr, ldc = _dense(C, 'C')
     F = C.size(1)
@@ -460,8 +470,8 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, c_is_zero=False):
     P = plan.partial(ldb, dev)
     args = (ctypes.byref(plan.c), A.col.data_ptr(), A.val.data_ptr(), A.n, A.m, bptr, ldb, cptr, ldc,
             P.data_ptr(), ldb, F, float(alpha))
-    if c_is_zero and beta == 1.0:
-        fn = _lib.dgnn_spmm_plan_zeroed_f32
+    if overwrite:
+        fn = _lib.dgnn_spmm_plan_overwrite_f32
     else:
         fn, args = _lib.dgnn_spmm_plan_f32, args + (float(beta),)
     if torch.cuda.current_device() == dev.index:         # the usual case: no device switch to pay for
@@ -486,15 +496,15 @@ def _pad_buffer(n, ld, dev):
     return buf
 
 
-def aggregate(A, H, Z, z_is_zero=False):
+def aggregate(A, H, Z, overwrite=False):
     """Z += A @ H for a CsrBlock A: the SpMM of one pipeline stage (models/gcn.py:28-29).
     H is any row-major [m, F] fp32 matrix; unless its rows already are 128-byte aligned it is
-    first copied into a padded block (dgnn_pad_rows_f32). ``z_is_zero``: Z was just zero-filled (the
-    first stage of an aggregation), so it is written without being read."""
+    first copied into a padded block (dgnn_pad_rows_f32). ``overwrite``: Z = A @ H instead (the first
+    stage of an aggregation: Z may be uninitialised, it is written without being read)."""
     F = Z.size(1)
     if not (H.dim() == 2 and H.size(1) == F):
         raise RuntimeError(f'aggregate: H{tuple(H.shape)} does not match Z{tuple(Z.shape)}')
     if H.stride(0) != padded_width(F) or H.data_ptr() % 128 != 0 or H.stride(1) != 1:
         with torch.cuda.device(H.device):
             H = pad_rows(H, _pad_buffer(H.size(0), padded_width(F), H.device))
-    spmm_plan(A, H, Z, 1.0, 1.0, c_is_zero=z_is_zero)
+    spmm_plan(A, H, Z, 1.0, 1.0, overwrite=overwrite)

@@ -117,6 +117,10 @@ int dgnn_gather_rows_f32(const float* src, int64_t lds, int32_t nsrc, const int3
  *   cut            device, int32[4 * ncut]: {row, pbase, pieces, 0} per cut run, grouped by stage
  *   stage_cut_off  HOST, int64[nstage + 1]
  *   npartial       rows the `partial` buffer must hold (sum of pieces over all cut runs)
+ *   covers_rows    1 if the FIRST stage lists every row of the block -- rows with nothing in the first
+ *                  column block as empty runs (k0 == k1, out = -1) -- so that a product which overwrites C
+ *                  (beta = 0, dgnn_spmm_plan_overwrite_f32) needs no zero fill: every row is stored by the
+ *                  first stage kernel or by its merge. 0: such a product zero-fills C first.
  * No counterpart in the reference (cuSPARSE keeps its own internal buffers, spmm.cpp:26-28).
  */
 typedef struct dgnn_plan {
@@ -127,6 +131,7 @@ typedef struct dgnn_plan {
   const int64_t* stage_cut_off;
   int64_t npartial;
   int32_t max_seg_len;      /* longest k1 - k0 in `seg` (> 0); bounds the critical path of a stage */
+  int32_t covers_rows;
 } dgnn_plan;
 
 /*
@@ -172,15 +177,16 @@ int dgnn_spmm_plan_f32(const dgnn_plan* plan, const int32_t* col, const float* v
                        int32_t F, float alpha, float beta, void* stream);
 
 /*
- * The same with beta = 1 for a C the caller knows to hold zeros (just memset, as the `z_loc = zeros` of
- * gcn.py:18 before its first stage): C = alpha * A * B, and the first stage kernel does not read C -- one
- * pass over C less, which is a tenth of the traffic on graphs with a few nonzeros per row. Same bits as
- * dgnn_spmm_plan_f32(beta = 1) on that C. (dgnn_spmm_plan_f32 with beta = 0 zero-fills and then does the same.)
+ * C = alpha * A * B for a C that need not be initialised (what the first stage of an aggregation wants: the
+ * `z_loc = zeros` of gcn.py:18 and its read-back disappear). With a plan that covers every row in its first
+ * stage nothing is zero-filled and C is never read: two passes over C less than zeros + accumulate, a tenth of
+ * the traffic on graphs with a few nonzeros per row. Otherwise C is zero-filled first. Same bits as
+ * dgnn_spmm_plan_f32(beta = 0). (dgnn_spmm_plan_f32 with beta = 0 takes the same route.)
  */
-int dgnn_spmm_plan_zeroed_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
-                              int32_t n, int32_t m, const float* B, int64_t ldb,
-                              float* C, int64_t ldc, float* partial, int64_t ldp,
-                              int32_t F, float alpha, void* stream);
+int dgnn_spmm_plan_overwrite_f32(const dgnn_plan* plan, const int32_t* col, const float* val,
+                                 int32_t n, int32_t m, const float* B, int64_t ldb,
+                                 float* C, int64_t ldc, float* partial, int64_t ldp,
+                                 int32_t F, float alpha, void* stream);
 
 /*
  * spmm_cusparse's operand list (row-sorted COO, spmm.cpp:16-17) on the fast kernel, for callers that hand

@@ -17,3 +17,7 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+# aggregation outputs are allocated uninitialised on the HIP path (the first stage product overwrites them):
+# under test they are filled with NaN first, so an element nobody stores cannot pass for a zero
+os.environ.setdefault('DGNN_POISON', '1')

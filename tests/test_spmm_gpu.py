@@ -209,10 +209,12 @@ def test_plan_path_matches_oracle(n, m, nnz, hubs, F, nstage, piece, alpha, beta
         assert np.array_equal(got[mask], want[mask])
 
 
+@pytest.mark.parametrize('builder', ['torch', 'device'])
 @pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece', [c[:7] for c in PLAN_CASES[:6] + PLAN_CASES[13:16]])
-def test_zero_filled_output_variant_gives_the_same_bits(n, m, nnz, hubs, F, nstage, piece):
-    """dgnn_spmm_plan_zeroed_f32 (the first stage does not read C) against dgnn_spmm_plan_f32(beta = 1) on a
-    zero-filled C -- contiguous and as a view of a padded buffer -- and through the aggregate helper."""
+def test_overwriting_product_needs_no_initialised_output(n, m, nnz, hubs, F, nstage, piece, builder):
+    """dgnn_spmm_plan_overwrite_f32 on a C full of NaN (contiguous, and as a view of a wider buffer) against
+    dgnn_spmm_plan_f32(beta = 1) on a zero-filled C: every row is stored by the first stage (empty rows and rows
+    with nothing in the first column block included), nothing is read, nothing past column F is touched."""
     import spmm_cpp
     rng = np.random.default_rng(5 * n + F)
     row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
@@ -220,24 +222,28 @@ def test_zero_filled_output_variant_gives_the_same_bits(n, m, nnz, hubs, F, nsta
     order = np.lexsort((col, row)); row, col, val = row[order], col[order], val[order]
     dev = torch.device('cuda:0')
     blk = _gpu_block(row, col, val, n, m)
-    plan = spmm_cpp.SegPlan(blk, nstage, piece)
+    plan = spmm_cpp.SegPlan(blk, nstage, piece) if builder == 'torch' else spmm_cpp.DevicePlan(blk, nstage, piece, F)
+    assert plan.c.covers_rows == 1
     Bp = spmm_cpp.pad_rows(torch.from_numpy(rng.standard_normal((m, F), dtype=np.float32)).to(dev))
     want = torch.zeros(n, F, device=dev)
     spmm_cpp.spmm_plan(blk, Bp, want, 1.0, 1.0, plan)
-    got = torch.zeros(n, F, device=dev)
-    spmm_cpp.spmm_plan(blk, Bp, got, 1.0, 1.0, plan, c_is_zero=True)
+    got = torch.full((n, F), float('nan'), device=dev)
+    spmm_cpp.spmm_plan(blk, Bp, got, 1.0, 1.0, plan, overwrite=True)
     assert torch.equal(got, want)
-    wide = torch.zeros(n, spmm_cpp.padded_width(F) + 32, device=dev)
-    spmm_cpp.spmm_plan(blk, Bp, wide[:, :F], 1.0, 1.0, plan, c_is_zero=True)
-    assert torch.equal(wide[:, :F], want) and (wide[:, spmm_cpp.padded_width(F):] == 0).all()
+    got.fill_(float('nan'))
+    spmm_cpp.spmm_plan(blk, Bp, got, 1.0, 0.0, plan)              # beta = 0 takes the same route
+    assert torch.equal(got, want)
+    wide = torch.full((n, spmm_cpp.padded_width(F) + 32), float('nan'), device=dev)
+    spmm_cpp.spmm_plan(blk, Bp, wide[:, :F], 1.0, 1.0, plan, overwrite=True)
+    assert torch.equal(wide[:, :F], want) and torch.isnan(wide[:, F:]).all()
     H = Bp[:, :F]
-    z = torch.zeros(n, F, device=dev)
-    spmm_cpp.aggregate(blk, H, z, z_is_zero=True)
+    z = torch.full((n, F), float('nan'), device=dev)
+    spmm_cpp.aggregate(blk, H, z, overwrite=True)
     z2 = torch.zeros(n, F, device=dev)
     spmm_cpp.aggregate(blk, H, z2)
     assert torch.equal(z, z2)
     spmm_cpp.aggregate(blk, H, z)                     # second stage: accumulates
-    spmm_cpp.aggregate(blk, H, z2, z_is_zero=False)
+    spmm_cpp.aggregate(blk, H, z2, overwrite=False)
     assert torch.equal(z, z2) and not torch.equal(z, want)
 
 
@@ -491,7 +497,8 @@ def test_device_built_plan_matches_oracle(n, m, nnz, hubs, F, nstage, piece, alp
     uncut = runs.max(axis=1) <= piece
     assert np.array_equal(got[uncut], want[uncut])
     nseg, ncut, npart = plan.counts()
-    assert nseg == int((runs > 0).sum() + (np.ceil(runs / piece)[runs > piece] - 1).sum())
+    empty_first = int((runs[:, 0] == 0).sum()) if nnz else 0       # listed in stage 0 as empty runs (covers_rows)
+    assert nseg == int((runs > 0).sum() + (np.ceil(runs / piece)[runs > piece] - 1).sum()) + empty_first
     assert ncut == int((runs > piece).sum()) and npart == int(np.ceil(runs / piece)[runs > piece].sum())
     again = torch.from_numpy(C0).to(dev)
     spmm_cpp.spmm_plan(blk, Bp, again, alpha, beta, spmm_cpp.DevicePlan(blk, nstage, piece, F))

@@ -76,6 +76,12 @@ def test_every_entry_form_matches_the_oracle(c):
     whole = lens <= c['piece']                         # rows no plan can have cut
     assert np.array_equal(got[whole], want[whole])
 
+    # 4. the overwriting product on an uninitialised (NaN) C equals beta = 0
+    if c['beta'] == 0.0:
+        buf = torch.full((n, F + c['pad_c']), float('nan'), device=dev)
+        spmm_cpp.spmm_plan(blk, Bp, buf[:, :F], c['alpha'], 1.0, plan, overwrite=True)
+        assert np.array_equal(buf[:, :F].cpu().numpy(), got) and torch.isnan(buf[:, F:]).all()
+
 
 @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(n=st.integers(1, 400), F=st.integers(1, 700), src_pad=st.integers(0, 5), extra=st.sampled_from([0, 4, 32]),
@@ -126,7 +132,8 @@ def test_device_built_plan_covers_every_nonzero_once(n, m, density, hubs, nstage
         live = seg[st_][seg[st_][:, 0] >= 0]
         live_total += len(live)
         for r, k0, k1, out in live:
-            assert 0 < k1 - k0 <= lay.piece and (row[k0:k1] == r).all()
+            assert 0 <= k1 - k0 <= lay.piece and (row[k0:k1] == r).all()
+            assert k1 > k0 or (st_ == 0 and out < 0)          # empty runs: only in stage 0 (covers_rows)
             assert (np.minimum(col[k0:k1] // cbw, lay.nstage - 1) == st_).all()
             covered[k0:k1] += 1
             if out >= 0:
@@ -134,5 +141,14 @@ def test_device_built_plan_covers_every_nonzero_once(n, m, density, hubs, nstage
         for r, pbase, cnt, _ in cut[st_][cut[st_][:, 2] > 0]:
             assert all(pieces_seen.get(p, 0) == 1 for p in range(pbase, pbase + cnt))
     assert (covered == 1).all() and live_total == nseg
+    assert plan.c.covers_rows == 1
+    cut_rows0 = {int(r_) for r_, pb, cnt, _ in cut[0][cut[0][:, 2] > 0]}
+    seen0 = np.zeros(n, dtype=np.int32)
+    for r, k0, k1, out in seg[0][seg[0][:, 0] >= 0]:
+        if out < 0:
+            seen0[r] += 1
+    for r in cut_rows0:
+        seen0[r] += 1
+    assert (seen0 == 1).all(), 'the first stage must store every row exactly once'
     assert sum(pieces_seen.values()) == npart == len(pieces_seen) and npart <= lay.npartial_max
     assert ncut == int((cut[:, :, 2] > 0).sum())

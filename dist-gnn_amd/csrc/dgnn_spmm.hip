@@ -755,7 +755,7 @@ int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_
 
 extern "C" {
 
-int dgnn_version(void) { return 200; }
+int dgnn_version(void) { return 210; }   // 210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32
 
 const char* dgnn_last_error(void) { return g_err; }
 

@@ -69,6 +69,10 @@ for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
+_ABI = 210                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+if _lib.dgnn_version() != _ABI:
+    raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
+                       'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')
 
 lib = _lib  # exposed for tests that call the C ABI directly
 

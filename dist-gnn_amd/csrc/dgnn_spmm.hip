@@ -333,8 +333,10 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   const int fbase = (chunk * L + li) * 4;
   int4 s = make_int4(-1, 0, 0, -1);            // {row, k0, k1, out}: out < 0 -> accumulate into C[row]
   if (sidx < nseg) s = seg[sidx];
-  const bool live = s.x >= 0;                   // row -1: an unused slot of a list sized by an upper bound
   const int kb = s.y, ke = s.z;
+  // row -1: an unused slot of a list sized by an upper bound; an empty run (the first stage lists every row,
+  // dgnn_plan.covers_rows) matters only to a product that overwrites C: it stores the row's zeros
+  const bool live = s.x >= 0 && (ke > kb || fresh);
   const bool direct = s.w < 0;
   // lanes past the padded width (last chunk of a width that is no multiple of the chunk) gather nothing
   const bool gathers = fbase < (int)ldb;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the distributed GCN aggregation path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or started plainly --
+                                                          it then launches its own N ranks)
 
 A *step* is one full GCN training epoch (forward, loss, backward, Adam) of the reference's training
 loop (light_dist_gnn/dist_train.py:36-45) on a dataset-shaped synthetic graph, 1D row-partitioned
@@ -50,7 +51,7 @@ def build_rank_graph(args, env):
     shape = synthetic.SHAPES[args.workload]
     n = int(shape[0] * args.scale)
     e = int(shape[1] * (args.scale ** 2 if args.scale < 1 else 1))
-    if args.lean or args.workload == 'papers':
+    if args.lean or args.workload == 'papers' or (env.world_size > 1 and not getattr(args, 'full_graph', False)):
         # every rank builds only its own part (no full normalised adjacency / feature matrix anywhere)
         rep = args.rep if args.model == 'GCN15D' else 1
         nblocks, block = env.world_size // rep, env.rank // rep
@@ -144,13 +145,41 @@ def cpu_baseline(g, widths, budget_s, rank_rows):
                 host_cpus=os.cpu_count())
 
 
+def cpu_epoch_baseline(workload, budget_s):
+    """Epoch time of the reference's CPU configuration (gloo, CPU tensors, SpMM = its fallback ``C.addmm_(A, B)``,
+    SURVEY 8d) on the box's host cores: tools/cpu_epoch.py in child processes that never touch the GPU. Cora shape at
+    P = 1 and 2 (BASELINE configs[0]); the bench workload's shape at 1/10 of its nodes (same density) at P = 1 -- the
+    full-size graph would take minutes per epoch on the host. Bounded: each child has a time limit."""
+    import subprocess
+    cores = host_threads()
+    runs = [('cora', 1.0, 1, 3), ('cora', 1.0, 2, 3)]
+    if workload in ('reddit', 'products'):
+        runs.append((workload, 0.1 if workload == 'reddit' else 0.03, 1, 1))
+    out = []
+    for wl, scale, P, epochs in runs:
+        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_epoch.py'), '--workload', wl, '--scale', str(scale),
+               '--nprocs', str(P), '--epochs', str(epochs), '--cores', str(cores),
+               '--layers', str({'reddit': 2, 'products': 3, 'cora': 2}[wl])]
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=max(60.0, 8 * budget_s))
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            out.append(json.loads(line[-1]) if r.returncode == 0 and line else
+                       dict(workload=wl, P=P, error=(r.stderr or 'no output')[-300:]))
+        except subprocess.TimeoutExpired:
+            out.append(dict(workload=wl, scale=scale, P=P, error='time limit'))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='reddit', choices=['reddit', 'products', 'cora', 'papers'])
-    ap.add_argument('--lean', action='store_true', help='build only this rank\'s part (always on for papers)')
+    ap.add_argument('--lean', action='store_true', help='build only this rank\'s part (always on for papers and for N > 1)')
+    ap.add_argument('--full-graph', action='store_true',
+                    help='N > 1: every rank builds the whole graph and keeps its part (the N = 1 route; same parts, N times the set-up work)')
     ap.add_argument('--layers', type=int, default=None)
     ap.add_argument('--hidden', type=int, default=256)
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the graph (debug only; invalidates the number)')
@@ -179,6 +208,19 @@ def main():
     limit = int(os.environ.get('DGNN_FAULT_TIMEOUT', 1500 if int(os.environ.get('WORLD_SIZE', 1)) > 1 else 0))
     if limit > 0:
         faulthandler.dump_traceback_later(limit, exit=True)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Started plainly (`python bench.py --gpus N`): launch the N ranks ourselves, as the reference's main.py
+        # spawns its own (light_dist_gnn/main.py:33). Child processes, started before this one has touched the GPU;
+        # this process only waits and hands their exit code on.
+        import socket
+        import subprocess
+        faulthandler.cancel_dump_traceback_later()
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     rank = int(os.environ.get('RANK', 0))
@@ -270,12 +312,18 @@ def main():
     stage_s = prof['stage_ms'] / 1e3
     launches = max(prof['stage_launches'], 1)
     achieved = alg / stage_s / 1e9 if stage_s > 0 else 0.0
-    traffic = None
+    # HBM-side bytes per stage launch come from a separate rocprofv3 --pmc pass of this same command
+    # (tools/profile_round.sh -> profiles/traffic.json): counters cannot be read from inside the run. The field
+    # repeats that stored measurement and says so; null when there is none for this workload.
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath) and world == 1 and args.workload == 'reddit' and args.scale == 1.0:
-        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        tj = json.load(open(tpath))
+        traffic = tj.get('hbm_bytes_per_launch')
+        traffic_source = ('stored: profiles/traffic.json, rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) '
+                          f"of `{tj.get('command', 'python bench.py')}` at {tj.get('commit', 'an earlier commit')}; not measured in this run")
     roofline = dict(bound='hbm', kernel='spmm_stage_kernel', achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(alg / launches),
                     avg_launch_ms=round(prof['stage_ms'] / launches, 4), launches=int(launches),
                     helper_kernels_ms_per_step=round(prof['other_ms'] / args.steps, 4),
@@ -313,6 +361,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         cpu = cpu_baseline(g, widths, args.cpu_budget, s)
+        cpu['epoch_s'] = cpu_epoch_baseline(args.workload, args.cpu_budget)
 
     if rank == 0:
         out = {

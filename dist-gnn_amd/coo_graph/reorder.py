@@ -1,0 +1,89 @@
+"""Locality reordering at data-preparation time: a pure relabelling of the nodes of a dataset dict.
+
+Counterpart of 1D_CAGNET/partition_torch_ready_data.py:15-57 (``metis_reorder``): there METIS assigns every node
+to one of P parts, the nodes are sorted by (part, old id) -- ``sorted_node_ids`` -- the edge list is relabelled through
+``id_mapping`` (old id -> position) and x / y / split are permuted with ``t[sorted_node_ids]``. METIS (and networkx's
+converter it is fed through) are not in this image; what is kept is the mechanism -- ``relabel`` below is that
+relabelling for ANY order -- with orderings that need no external package, computed with torch ops on the device that
+holds the edge list:
+
+  'bfs'      breadth-first numbering from the highest-degree node (Cuthill-McKee without the degree tie-break): a
+             node's neighbours get nearby ids, so a 1D row block references fewer distinct rows of the other blocks
+             (needed-rows transfer) and a lane group's gathers stay closer together (L2);
+  'degree'   descending degree (hub rows and hub columns first).
+
+A reordered dataset is a DIFFERENT input with the same answer up to the permutation: results are permuted, not
+changed (tests/test_reorder.py). ``prepare_data.py --reorder bfs`` writes it as dataset ``<name>_reorder``, the tag
+the reference uses for its reordered Reddit (light_dist_gnn/coo_graph/datasets.py:93).
+"""
+import torch
+
+
+def relabel(d, order):
+    """``order[i]`` = old id of the node that becomes node i (the reference's ``sorted_node_ids``). Returns a new
+    dataset dict: edge list relabelled (same edge order), per-node tensors permuted."""
+    n = d['num_nodes']
+    order = order.long()
+    if order.numel() != n or not torch.equal(torch.sort(order).values, torch.arange(n, device=order.device)):
+        raise ValueError('relabel: order is not a permutation of the node ids')
+    new_id = torch.empty_like(order)
+    new_id[order] = torch.arange(n, device=order.device)              # id_mapping: old id -> new id
+    out = dict(d)
+    ei = d['edge_index']
+    out['edge_index'] = new_id.to(ei.device)[ei.long()].to(ei.dtype)
+    for k in ('features', 'labels', 'train_mask', 'val_mask', 'test_mask'):
+        if k in d and d[k] is not None:
+            out[k] = d[k][order.to(d[k].device)]
+    out['node_order'] = order
+    return out
+
+
+def degree_order(edge_index, n):
+    ei = edge_index.long()
+    deg = torch.bincount(ei[0], minlength=n) + torch.bincount(ei[1], minlength=n)
+    return torch.argsort(deg, descending=True, stable=True)
+
+
+def bfs_order(edge_index, n, max_levels=10000):
+    """Breadth-first numbering: level by level from the highest-degree node; inside a level by the position of the
+    earliest-numbered neighbour in the previous level, ties by old id. Nodes the search does not reach (other
+    components, isolated nodes) follow, by descending degree. Deterministic."""
+    ei = edge_index.long()
+    dev = ei.device
+    src, dst = torch.cat([ei[0], ei[1]]), torch.cat([ei[1], ei[0]])   # treat the graph as undirected
+    deg = torch.bincount(src, minlength=n)
+    pos = torch.full((n,), -1, dtype=torch.long, device=dev)
+    big = n + 1
+    start = int(torch.argmax(deg))
+    pos[start] = 0
+    placed = 1
+    frontier = torch.zeros(n, dtype=torch.bool, device=dev)
+    frontier[start] = True
+    for _ in range(max_levels):
+        on = frontier[src] & (pos[dst] < 0)
+        if not bool(on.any()):
+            break
+        cand = torch.full((n,), big, dtype=torch.long, device=dev)
+        cand.scatter_reduce_(0, dst[on], pos[src[on]], reduce='amin')
+        new = torch.nonzero(cand < big).flatten()
+        new = new[torch.argsort(cand[new], stable=True)]              # nonzero() is ascending: ties by old id
+        pos[new] = placed + torch.arange(new.numel(), device=dev)
+        placed += new.numel()
+        frontier = torch.zeros(n, dtype=torch.bool, device=dev)
+        frontier[new] = True
+    rest = torch.nonzero(pos < 0).flatten()
+    if rest.numel():
+        rest = rest[torch.argsort(deg[rest], descending=True, stable=True)]
+        pos[rest] = placed + torch.arange(rest.numel(), device=dev)
+    order = torch.empty(n, dtype=torch.long, device=dev)
+    order[pos] = torch.arange(n, device=dev)
+    return order
+
+
+ORDERS = {'bfs': bfs_order, 'degree': degree_order}
+
+
+def reorder_dataset(d, how):
+    if how not in ORDERS:
+        raise ValueError(f'unknown reordering {how!r}: expected one of {sorted(ORDERS)}')
+    return relabel(d, ORDERS[how](d['edge_index'], d['num_nodes']))

@@ -77,14 +77,29 @@ def make_dataset(shape='cora', seed=0, device='cpu', num_nodes=None, num_edges=N
     edge_index = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
     out = {"edge_index": edge_index, "num_nodes": n, "num_edges": edge_index.size(1), "num_classes": c}
     if with_features:
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(seed + 1)
-        if shape == 'cora':   # binary bag-of-words, ~1.27 % dense
-            feats = (torch.rand(n, f, generator=gen, device=dev) < 0.0127).to(torch.float32)
-        else:
-            feats = torch.randn(n, f, generator=gen, device=dev)
-        out["features"] = feats
+        out["features"] = feature_rows(shape, f, seed, 0, n, dev)
     out.update(_labels_and_masks(n, c, tf, seed, dev))
+    return out
+
+
+FEATURE_TILE = 1 << 16
+
+
+def feature_rows(shape, f, seed, r0, r1, dev):
+    """Raw features of rows [r0, r1) of the synthetic dataset. Rows are drawn in tiles of FEATURE_TILE rows, each
+    tile from its own seeded stream, so a rank that builds only its own part (make_partition) gets exactly the
+    rows the full dataset (make_dataset) holds, whatever the number of parts."""
+    out = torch.empty(max(r1 - r0, 0), f, dtype=torch.float32, device=dev)
+    gen = torch.Generator(device=dev)
+    for t in range(r0 // FEATURE_TILE, -(-r1 // FEATURE_TILE) if r1 > r0 else 0):
+        t0 = t * FEATURE_TILE
+        gen.manual_seed((seed + 1) * 1000003 + t)
+        if shape == 'cora':   # binary bag-of-words, ~1.27 % dense
+            tile = (torch.rand(FEATURE_TILE, f, generator=gen, device=dev) < 0.0127).to(torch.float32)
+        else:
+            tile = torch.randn(FEATURE_TILE, f, generator=gen, device=dev)
+        a, b = max(r0, t0), min(r1, t0 + FEATURE_TILE)
+        out[a - r0:b - r0] = tile[a - t0:b - t0]
     return out
 
 
@@ -105,9 +120,9 @@ def make_partition(shape, rank, num_parts, seed=0, device='cpu', num_nodes=None,
     built without ever holding the whole normalised adjacency or the whole feature matrix: for graphs the
     size of ogbn-papers100M (111 M nodes, 1.6 B entries, BASELINE config 4) every rank builds its own slab
     on its own GPU. The edge keys (8 B per undirected edge) and the degree vector are the only full-graph
-    arrays. Adjacency slab, labels and masks are identical to the full path (tests/test_host_golden.py);
-    the features of a row block come from that block's own seeded stream (the full path draws all rows
-    from one stream), already row-normalised as preprocess() does.
+    arrays. Adjacency slab, labels, masks and features are identical to the full path
+    (tests/test_host_golden.py; features are drawn per row tile, feature_rows), the features already
+    row-normalised as preprocess() does.
     """
     n, e, f, c, tf = SHAPES[shape]
     n, e, f, c, tf = num_nodes or n, num_edges or e, num_features or f, num_classes or c, train_fraction or tf
@@ -136,12 +151,7 @@ def make_partition(shape, rank, num_parts, seed=0, device='cpu', num_nodes=None,
     vals = (d[rows] * 1.0) * d[cols]                             # (d_i * a_ij) * d_j with a_ij = 1
     adj = torch.sparse_coo_tensor(torch.stack([rows - r0, cols]), vals, (s, s * P), is_coalesced=True)
     del rows, cols, d
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed * 1000003 + 17 * rank + 1)
-    if shape == 'cora':
-        feats = (torch.rand(r1 - r0, f, generator=gen, device=dev) < 0.0127).to(torch.float32)
-    else:
-        feats = torch.randn(r1 - r0, f, generator=gen, device=dev)
+    feats = feature_rows(shape, f, seed, r0, r1, dev)
     feats = feats / feats.sum(1, keepdim=True).clamp(min=1)
     if feats.size(0) < s:
         feats = torch.cat([feats, feats.new_zeros(s - feats.size(0), f)])

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
   // fetched up front, all loads in flight together, and parked in LDS. Vector loads return in order, so
   // a cold load issued between gather rounds would stall every younger (L2-hit) gather behind it; this
   // way a strip pays that latency once. The strip is private to the group (one wave, in-order LDS), so
-  // no barrier separates the phases or consecutive strips.
+  // no s_barrier separates the phases or consecutive strips -- only wave-scope fences for the compiler.
 #pragma unroll 1
   for (int sb0 = kb; sb0 < ke; sb0 += SEGM) {
     const int se = min(sb0 + SEGM, ke);
@@ -381,18 +381,27 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
         ent[(li + (t0 + t) * L) & (SEGM - 1)] = make_uint2(x, __float_as_uint(alpha * __uint_as_float(vy[t])));
       }
     }
+    // The strip is handed from the lanes that wrote it to the lanes that read it inside one wave: LDS is in
+    // order per wave, but the compiler has to be told that these stores and the loads below communicate.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // Phase 2: gather rounds, U rows of B in flight per lane. Lanes past the padded width (last chunk
     // of a width that is no multiple of the chunk) sit the rounds out: fewer lanes for the address unit.
-    if (!gathers) continue;
-    int j = 0;
+    if (gathers) {
+      int j = 0;
 #pragma unroll 1
-    for (; j + U <= len; j += U) gather_round<U, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);
-    // the leftover (< U entries) goes in rounds of 4, 2, 1: at most three memory latencies instead of one
-    // per entry -- on sparse graphs most runs ARE leftover
-    if constexpr (U > 4) if (j + 4 <= len) { gather_round<4, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 4; }
-    if constexpr (U > 2) if (j + 2 <= len) { gather_round<2, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 2; }
+      for (; j + U <= len; j += U) gather_round<U, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);
+      // the leftover (< U entries) goes in rounds of 4, 2, 1: at most three memory latencies instead of one
+      // per entry -- on sparse graphs most runs ARE leftover
+      if constexpr (U > 4) if (j + 4 <= len) { gather_round<4, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 4; }
+      if constexpr (U > 2) if (j + 2 <= len) { gather_round<2, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 2; }
 #pragma unroll 1
-    for (; j < len; ++j) gather_round<1, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);   // one trip for U = 2, 4, 8
+      for (; j < len; ++j) gather_round<1, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);   // one trip for U = 2, 4, 8
+    }
+    // ... and the next strip's stores must not pass this strip's loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 
   if (live) {
@@ -400,6 +409,191 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
       if (fbase < ldp) *reinterpret_cast<float4*>(dst) = make_float4(a01.x, a01.y, a23.x, a23.y);
     } else {
       c_store<VWC>(dst, fbase, F, a01, a23);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Hot-tile variant of the stage kernel: "feature tiles of H_j staged in LDS" (north_star).
+//
+// The stage kernel above is bound by the texture-address / L1 path: every nonzero pulls its slice of a B row
+// through it at 64 B/clk/CU, L2 hit or not. The only faster source on a CU is the LDS (256 B/clk/CU for
+// ds_read_b128). A graph with hub columns lets it carry a large share of the reads: the plan names, per
+// column-block stage, the T most referenced columns (`hot_cols`) and lists every run with its hot entries first
+// (column replaced by the slot 0..T-1 in the tile) and its other entries after them. One workgroup of 16 waves
+// per CU keeps the [T x CH] slice of those B rows for its feature chunk in LDS (128 KiB) and walks segment blocks
+// persistently (the same chunk-major, XCD-aware, class-balanced order as the stage kernel, strided over the
+// resident workgroups); per run a lane group first takes the hot entries out of the tile (ds_read_b128, no
+// address unit), then gathers the others as the stage kernel does. The tile is reloaded only when the
+// workgroup moves on to the next feature chunk.
+//
+// Accumulation order of an output element inside a stage: its hot nonzeros in ascending column order, then
+// the others in ascending column order (one chain, one lane, fused multiply-adds: deterministic; the same
+// bits as the strict chain over the plan's own (permuted) entry order, which is what the tests check).
+// ---------------------------------------------------------------------------------------
+constexpr int HOT_WAVES = 16;                 // waves per workgroup (1024 threads, one workgroup per CU)
+constexpr int HOT_STRIP = 64;                 // entries of a run parked per lane group and trip
+constexpr int HOT_TILE_FLOATS = 32768;        // 128 KiB of B rows
+
+template <int R>
+__device__ __forceinline__ void hot_round(const uint2* ent, int j, const char* tile_lane, f32x2& a01, f32x2& a23) {
+  uint2 e[R];
+  if constexpr (R == 1) {
+    e[0] = ent[j];
+  } else {
+#pragma unroll
+    for (int h = 0; h < R / 2; ++h) {
+      const uint4 t = *reinterpret_cast<const uint4*>(&ent[j + 2 * h]);
+      e[2 * h] = make_uint2(t.x, t.y);
+      e[2 * h + 1] = make_uint2(t.z, t.w);
+    }
+  }
+  float4 bb[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) bb[u] = *reinterpret_cast<const float4*>(tile_lane + e[u].x);
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const float v = __uint_as_float(e[u].y);
+    const f32x2 vv = {v, v};
+    a01 = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01);
+    a23 = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23);
+  }
+}
+
+template <int L, int U, int VWC, bool WIDE>
+__global__ __launch_bounds__(HOT_WAVES * 64) void spmm_hot_kernel(
+    const int4* __restrict__ seg, const int32_t* __restrict__ seg_hot, int32_t nseg, uint32_t nsegblocks, uint32_t nbv,
+    const int32_t* __restrict__ col, const float* __restrict__ val, const int32_t* __restrict__ hot_cols,
+    const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+    float* __restrict__ P, int64_t ldp, int32_t F, float alpha, uint32_t k, int fresh, int dbg) {
+  constexpr int G = 64 / L;
+  constexpr int CH = 4 * L;                      // floats of a feature chunk
+  constexpr int T = HOT_TILE_FLOATS / CH;        // hot rows: 512 (L = 16) or 256 (L = 32)
+  constexpr int PER = HOT_STRIP / L;             // strip entries loaded per lane and trip
+  static_assert(U % 2 == 0, "entries are read two per ds_read_b128");
+  __shared__ float4 tile[T * L];
+  __shared__ uint2 ent_all[HOT_WAVES][G][HOT_STRIP];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L;
+  const int li = lane % L;
+  uint2* const ent = ent_all[wave][g];
+  const char* const tile_lane = reinterpret_cast<const char*>(tile) + li * 16;
+  const uint32_t ldb_bytes = (uint32_t)ldb * 4u;
+  const char* const Bbytes = reinterpret_cast<const char*>(B);
+
+  // virtual block -> (feature chunk, segment block): the stage kernel's order over a virtual grid of nbv blocks
+  // (nbv % 8 == 0), of which this workgroup takes blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x % 8 == 0, so
+  // all of them carry this workgroup's XCD label and walk that XCD's contiguous share front to back)
+  const uint32_t q = nbv >> 3, xcd = blockIdx.x & 7;
+  int cur_chunk = -1;
+#pragma unroll 1
+  for (uint32_t vb = blockIdx.x; vb < nbv; vb += gridDim.x) {
+    const uint32_t w = xcd * q + (vb >> 3);
+    const uint32_t chunk = w / nsegblocks;
+    const uint32_t p = w - chunk * nsegblocks;
+    uint32_t sb = p;
+    if (k > 1) {
+      const uint32_t qc = nsegblocks / k;
+      const uint32_t v0 = xcd * q, c0 = chunk * nsegblocks;
+      const uint32_t lo = (v0 > c0 ? v0 - c0 : 0u);
+      const uint32_t hi = min(v0 + q - c0, nsegblocks);
+      const uint32_t j0 = lo / qc, ncl = hi / qc - j0;
+      const uint32_t t = p - lo;
+      sb = (t / ncl) * k + j0 + t % ncl;
+    }
+    const int fbase = (chunk * L + li) * 4;
+    const bool gathers = fbase < (int)ldb;       // lanes past the padded width read and gather nothing
+    const uint32_t loff = (uint32_t)fbase * 4u;
+    if ((int)chunk != cur_chunk) {               // uniform over the workgroup: vb depends on blockIdx only
+      __syncthreads();                           // nobody still reads the previous chunk's tile
+#pragma unroll 1
+      for (int r = wave * G + g; r < T; r += HOT_WAVES * G) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gathers) v = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)hot_cols[r] * ldb_bytes + loff));
+        tile[r * L + li] = v;
+      }
+      __syncthreads();
+      cur_chunk = (int)chunk;
+    }
+    const int64_t sidx = ((int64_t)sb * HOT_WAVES + wave) * G + g;
+    int4 s = make_int4(-1, 0, 0, -1);
+    int kh = 0;
+    if (sidx < nseg) { s = seg[sidx]; kh = seg_hot[sidx]; }
+    const int kb = s.y, ke = s.z;
+    const bool live = s.x >= 0 && (ke > kb || fresh);
+    const bool direct = s.w < 0;
+    float* const dst = direct ? (C + (int64_t)s.x * ldc + fbase) : (P + (int64_t)s.w * ldp + fbase);
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    if (live && direct && !fresh) c_load<VWC>(dst, fbase, F, a01, a23);
+
+    // ---- hot entries [kb, kh): (slot, val) -> (byte offset of the tile row, alpha*val), read back from the tile
+#pragma unroll 1
+    for (int sb0 = kb; sb0 < ((dbg & 2) ? kb : kh); sb0 += HOT_STRIP) {
+      const int se = min(sb0 + HOT_STRIP, kh);
+      const int len = se - sb0;
+      uint32_t cx[PER], vy[PER];
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        const int kk = min(sb0 + li + t * L, se - 1);
+        cx[t] = (uint32_t)col[kk];
+        vy[t] = __float_as_uint(val[kk]);
+      }
+#pragma unroll
+      for (int t = 0; t < PER; ++t)
+        ent[li + t * L] = make_uint2(cx[t] * (uint32_t)(CH * 4), __float_as_uint(alpha * __uint_as_float(vy[t])));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (gathers) {
+        int j = 0;
+#pragma unroll 1
+        for (; j + 8 <= len; j += 8) hot_round<8>(ent, j, tile_lane, a01, a23);
+        if (j + 4 <= len) { hot_round<4>(ent, j, tile_lane, a01, a23); j += 4; }
+        if (j + 2 <= len) { hot_round<2>(ent, j, tile_lane, a01, a23); j += 2; }
+        if (j < len) hot_round<1>(ent, j, tile_lane, a01, a23);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the other entries [kh, ke): gathered through the vector-memory path, as in the stage kernel
+#pragma unroll 1
+    for (int sb0 = max(kh, kb); sb0 < ((dbg & 1) ? kb : ke); sb0 += HOT_STRIP) {
+      const int se = min(sb0 + HOT_STRIP, ke);
+      const int len = se - sb0;
+      uint32_t cx[PER], vy[PER];
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        const int kk = min(sb0 + li + t * L, se - 1);
+        cx[t] = (uint32_t)col[kk];
+        vy[t] = __float_as_uint(val[kk]);
+      }
+#pragma unroll
+      for (int t = 0; t < PER; ++t)
+        ent[li + t * L] = make_uint2(WIDE ? cx[t] : cx[t] * ldb_bytes, __float_as_uint(alpha * __uint_as_float(vy[t])));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (gathers) {
+        int j = 0;
+#pragma unroll 1
+        for (; j + U <= len; j += U) gather_round<U, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);
+        if constexpr (U > 4) if (j + 4 <= len) { gather_round<4, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 4; }
+        if constexpr (U > 2) if (j + 2 <= len) { gather_round<2, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23); j += 2; }
+#pragma unroll 1
+        for (; j < len; ++j) gather_round<1, WIDE>(ent, j, Bbytes, ldb_bytes, loff, a01, a23);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    if (live) {
+      if (!direct) {
+        if (fbase < ldp) *reinterpret_cast<float4*>(dst) = make_float4(a01.x, a01.y, a23.x, a23.y);
+      } else {
+        c_store<VWC>(dst, fbase, F, a01, a23);
+      }
     }
   }
 }
@@ -753,11 +947,46 @@ int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_
   return DGNN_OK;
 }
 
+
+template <int L, int U>
+int launch_hot(int vwc, bool wide, const int4* seg, const int32_t* seg_hot, int32_t nseg, const int32_t* col, const float* val,
+               const int32_t* hot_cols, const float* B, int64_t ldb, float* C, int64_t ldc, float* P, int64_t ldp,
+               int32_t F, float alpha, bool fresh, hipStream_t s) {
+  constexpr int G = 64 / L;
+  int64_t nsegblocks = ((int64_t)nseg + HOT_WAVES * G - 1) / (HOT_WAVES * G);
+  const int64_t nchunks = (ldb / 4 + L - 1) / L;
+  int64_t gcd8 = 8;
+  while (nchunks % gcd8) gcd8 >>= 1;
+  const uint32_t k = (uint32_t)(8 / gcd8);
+  nsegblocks = (nsegblocks + k - 1) / k * k;
+  const int64_t nbv = nsegblocks * nchunks;                  // a multiple of 8
+  if (nbv <= 0 || nbv > 0x7fffffffLL) return fail(DGNN_E_BADARG, "hot stage grid out of range%s (%lld)", "", nbv);
+  static int cus = 0;                                        // one workgroup per CU (its LDS is taken whole)
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    DGNN_HIP(hipGetDevice(&dev));
+    DGNN_HIP(hipGetDeviceProperties(&prop, dev));
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / 8 * 8 : 256;
+    if (cus < 8) cus = 8;
+  }
+  const unsigned grid = (unsigned)(nbv < cus ? nbv : cus);
+  ProfScope prof(s, 0);
+#define DGNN_HOT(VWC, WIDE)                                                                                     \
+  hipLaunchKernelGGL((spmm_hot_kernel<L, U, VWC, WIDE>), dim3(grid), dim3(HOT_WAVES * 64), 0, s, seg, seg_hot, nseg, \
+                     (uint32_t)nsegblocks, (uint32_t)nbv, col, val, hot_cols, B, ldb, C, ldc, P, ldp, F, alpha, k, fresh ? 1 : 0, \
+                     g_variant >= 200 && g_variant < 204 ? g_variant - 200 : 0)
+  if (wide) { if (vwc == 4) DGNN_HOT(4, true); else if (vwc == 2) DGNN_HOT(2, true); else DGNN_HOT(1, true); }
+  else { if (vwc == 4) DGNN_HOT(4, false); else if (vwc == 2) DGNN_HOT(2, false); else DGNN_HOT(1, false); }
+#undef DGNN_HOT
+  DGNN_HIP(hipGetLastError());
+  return DGNN_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int dgnn_version(void) { return 210; }   // 210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32
+int dgnn_version(void) { return 225; }   // 225: dgnn_plan.hot_rows / hot_cols / seg_hot (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 
@@ -922,6 +1151,8 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
                               float* partial, int64_t ldp, int32_t F,
                               float alpha, float beta, void* stream) {
   if (n == 0 || F == 0) return DGNN_OK;
+  if (nnz == 0)                                   // nothing to plan: beta scaling only, as dgnn_spmm_coo_f32 does
+    return dgnn_spmm_csr_f32(rowptr_ws, col, val, n, m, 0, B, ldb, C, ldc, F, alpha, beta, stream);
   dgnn_plan_layout d;
   int rc = dgnn_plan_layout_for(n, m, nnz, ldb, 0, 0, &d);
   if (rc != DGNN_OK) return rc;
@@ -935,6 +1166,7 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
   plan.nstage = d.nstage; plan.seg = plan_ws + d.hdr_ints; plan.stage_seg_off = seg_off;
   plan.cut = plan_ws + d.hdr_ints + 4 * d.nstage * d.nseg_max; plan.stage_cut_off = cut_off;
   plan.npartial = d.npartial_max; plan.max_seg_len = d.piece; plan.covers_rows = 1;
+  plan.hot_rows = 0; plan.hot_cols = nullptr; plan.seg_hot = nullptr;
   return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
 }
 
@@ -981,7 +1213,17 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
       // better for narrow blocks only while XCD shares were unbalanced (more chunks hid it); with balanced
       // shares they are 5-25 % slower at every width measured. Kept behind the variant knob for A/B runs.
       const bool narrow = (g_variant == 8);
-      if (narrow)
+      if (plan->hot_rows > 0) {
+        if ((plan->hot_rows != 256 && plan->hot_rows != 512) || !plan->hot_cols || !plan->seg_hot)
+          return fail(DGNN_E_BADARG, "spmm_plan: hot-tile plan needs hot_rows 256 or 512, hot_cols and seg_hot%s", "");
+        const int32_t* hc = plan->hot_cols + (int64_t)st * plan->hot_rows;
+        const int32_t* sh = plan->seg_hot + s0;
+        const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100 : 4;
+#define DGNN_LAUNCH_HOT(LL, UU) launch_hot<LL, UU>(vwc, wide, seg, sh, ns, col, val, hc, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s)
+        if (plan->hot_rows == 512) rc = (u == 2) ? DGNN_LAUNCH_HOT(16, 2) : (u == 8) ? DGNN_LAUNCH_HOT(16, 8) : DGNN_LAUNCH_HOT(16, 4);
+        else rc = (u == 2) ? DGNN_LAUNCH_HOT(32, 2) : (u == 8) ? DGNN_LAUNCH_HOT(32, 8) : DGNN_LAUNCH_HOT(32, 4);
+#undef DGNN_LAUNCH_HOT
+      } else if (narrow)
         rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s);
       else {
         // Gathers in flight per lane: 4 while one stage's slice of B fits the 256 MiB Infinity Cache, 2 when

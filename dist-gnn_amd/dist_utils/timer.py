@@ -26,10 +26,10 @@ class TimerCtx:
 
     def __enter__(self):
         if self.sync:
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(self.timer.env.device)
         if self.cuda and not self.sync:
             if self.stream is None:              # looked up once per region (the lookup costs more than a record)
-                self.stream = torch.cuda.current_stream()
+                self.stream = torch.cuda.current_stream(self.timer.env.device)
             self.ev0 = torch.cuda.Event(enable_timing=True)
             self.ev0.record(self.stream)
         self.t0 = time.time()
@@ -47,7 +47,7 @@ class TimerCtx:
                 pairs[:] = [p for p, f in zip(pairs, flags) if not f]
         else:
             if self.sync:
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(self.timer.env.device)
             self.timer.duration_dict[self.key] += time.time() - self.t0
         self.timer.count_dict[self.key] += 1
 
@@ -56,7 +56,10 @@ class DistTimer:
     def __init__(self, env):
         self.env = env
         self.sync = os.environ.get('DGNN_TIMER_SYNC', '0') == '1'
-        self.cuda_ok = torch.cuda.is_available()
+        # events only when the job's tensors live on a GPU: a gloo/CPU run on a GPU box must not time an idle GPU
+        # stream (nor create a GPU context in every rank)
+        dev = getattr(env, 'device', None)
+        self.cuda_ok = torch.cuda.is_available() and dev is not None and dev.type == 'cuda'
         self.start_time_dict = {}
         self.duration_dict = defaultdict(float)
         self.count_dict = defaultdict(int)
@@ -65,7 +68,7 @@ class DistTimer:
     def resolve(self):
         """Fold recorded HIP event pairs into duration_dict (synchronises once)."""
         if any(self.pending.values()):
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(self.env.device)
         for key, pairs in self.pending.items():
             self.duration_dict[key] += sum(a.elapsed_time(b) for a, b in pairs) / 1e3
             pairs.clear()

@@ -95,9 +95,35 @@ class NeededRows:
         self.send_idx = list(got.split(out_split))
         self.send_idx_all = got                             # the same lists back to back, in rank order
         self.block_rows = adj_parts[0].size(1)
+        self.rank, self._compact = rank, None
         # the same number on every rank (K is): ranks must agree on whether this form is worth trying
         self.fraction = float(self.K.sum()) / max(1, P * (P - 1) * self.block_rows)
         self.local_fraction = float(self.K[rank].sum()) / max(1, (P - 1) * self.block_rows)
+
+    def compact_slab(self):
+        """The rank's whole row slab as ONE matrix over the compact operand
+        [needed rows of H_0 | ... | all rows of the own block | ... | needed rows of H_(P-1)] (source order), built on
+        first use: one SpMM instead of P, z written once instead of read and written per source. Columns are
+        renumbered monotonically inside each block and the blocks keep their source order, so every row keeps its
+        nonzeros in the order of the P block products -- same chain, same bits. Returns (matrix, row offset of every
+        source in the operand, operand rows, send index list with the own block's rows in place)."""
+        if self._compact is None:
+            P, rank = len(self.blocks), self.rank
+            dev = self.blocks[0].device
+            offs, at = [], 0
+            for src in range(P):
+                offs.append(at)
+                at += self.block_rows if src == rank else int(self.cols[src].numel())
+            rows = torch.cat([b.indices()[0] for b in self.blocks])
+            cols = torch.cat([b.indices()[1] + offs[src] for src, b in enumerate(self.blocks)])
+            vals = torch.cat([b.values() for b in self.blocks])
+            order = torch.argsort(rows * max(at, 1) + cols)
+            slab = torch.sparse_coo_tensor(torch.stack([rows[order], cols[order]]), vals[order],
+                                           (self.blocks[0].size(0), max(at, 1)), is_coalesced=True)
+            own = torch.arange(self.block_rows, dtype=torch.int32, device=dev)
+            send_idx = torch.cat(list(self.send_idx[:rank]) + [own] + list(self.send_idx[rank + 1:]))
+            self._compact = (slab, offs, at, send_idx)
+        return self._compact
 
     @staticmethod
     def fraction_needed(adj_parts, group):
@@ -221,9 +247,10 @@ class StagePipeline:
     receivers' SpMMs read it in place; otherwise the [s, F] block travels as is and each receiver
     pads its copy (dgnn_pad_rows_f32).
 
-    ``cache_input`` (default on, DGNN_CACHE_INPUT=0 disables): the layer-1 forward pass moves the
-    *input features*, which do not change between epochs. When the same tensor (same storage,
-    same version counter) is aggregated again under the same tag, the blocks received last time
+    ``cache_input`` (opt-in, DGNN_CACHE_INPUT=1; the reference's plain GCN re-sends every epoch and only its
+    CachedGCN reuses blocks): the layer-1 forward pass moves the
+    *input features*, which do not change between epochs. When the same tensor OBJECT, unwritten since (the
+    entry holds a reference to it and its version counter), is aggregated again under the same tag, the blocks received last time
     are reused and nothing is sent -- lossless, results identical, one of the 2L transfers of an
     epoch removed. (The reference's plain GCN re-sends them every epoch; its CachedGCN does this
     by policy, cached_gcn.py:26.)
@@ -235,7 +262,7 @@ class StagePipeline:
             raise ValueError(f'DGNN_PIPELINE={self.mode!r}: expected auto, bcast, allgather, agpipe, agpipe4, needed, '
                              'needed_a2a or needed_a2a2')
         self.inflight = max(1, int(inflight or os.environ.get('DGNN_INFLIGHT', 2)))   # 1 = no overlap (debugging)
-        self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '1') == '1') if cache_input is None else cache_input
+        self.cache_input = (os.environ.get('DGNN_CACHE_INPUT', '0') == '1') if cache_input is None else cache_input
         self._bufs = {}
         self._input_cache = {}         # tag -> (key of the source tensor, [block per src])
         self.transfers = 0             # blocks actually moved (tests / logs)
@@ -253,8 +280,10 @@ class StagePipeline:
         return have
 
     @staticmethod
-    def _tensor_key(t):
-        return (t.data_ptr(), t._version, tuple(t.shape), t.device)
+    def _same_input(hit, t):
+        """The cache entry holds the source tensor itself (so its storage cannot be freed and handed to another
+        tensor while the entry lives) and its version counter at the time: a hit needs the same object, unwritten."""
+        return hit[0] is t and hit[1] == t._version
 
     @staticmethod
     def _wire_width(feat):
@@ -495,6 +524,14 @@ class StagePipeline:
         step = (-(-F // chunks) + 31) // 32 * 32 if chunks > 1 else F
         bounds = [(c0, min(c0 + step, F)) for c0 in range(0, F, step)]
         pending = {}
+        # Fused (default, DGNN_FUSED_SLAB=0 turns it off): the own block travels through the all-to-all as this
+        # rank's message to itself (a device-local copy), so the receive buffer IS the compact operand in source
+        # order and ONE SpMM of the compact row slab replaces the P block products (see NeededRows.compact_slab).
+        fused = self.fused_slab and [src for src, _ in stages] == list(range(P))
+        send_idx = nr.send_idx_all
+        if fused:
+            slab, _, _, send_idx = nr.compact_slab()
+            in_rows[rank] = out_rows[rank] = nr.block_rows
 
         def post(c):
             c0, c1 = bounds[c]
@@ -503,7 +540,7 @@ class StagePipeline:
             send = self._buffers((max(1, sum(out_rows)), ld), feat, 1, f'a2a-send{c}')[0][:sum(out_rows)]
             recv = self._buffers((max(1, sum(in_rows)), ld), feat, 1, f'a2a-recv{c}')[0][:sum(in_rows)]
             if sum(out_rows):
-                _gather_rows(feat[:, c0:c1] if w != F else feat, nr.send_idx_all, send)
+                _gather_rows(feat[:, c0:c1] if w != F else feat, send_idx, send)
             work = dist.all_to_all_single(recv, send, output_split_sizes=in_rows, input_split_sizes=out_rows,
                                           group=group, async_op=True)
             pending[c] = (work, recv, w, ld)
@@ -515,6 +552,10 @@ class StagePipeline:
             work, recv, w, ld = pending.pop(c)
             with timer.timing_cuda('broadcast'):
                 work.wait()
+            if fused:
+                with timer.timing_cuda('spmm'):
+                    spmm(slab, recv[:, :w] if ld != w else recv, z[:, c0:c1] if w != F else z, fresh=True)
+                continue
             acc = _Sum(z[:, c0:c1] if w != F else z)
             at = 0
             with timer.timing_cuda('spmm'):
@@ -529,7 +570,7 @@ class StagePipeline:
                         at += k
                 acc.done()
         self.transfers += P
-        self.rows_moved += sum(in_rows)
+        self.rows_moved += sum(in_rows) - (nr.block_rows if fused else 0)
         self.rows_full += nr.block_rows * (P - 1)
         return z
 
@@ -547,7 +588,10 @@ class StagePipeline:
             forms += ['allgather'] + (['agpipe'] if feat.size(1) > 32 else [])   # graphs cannot afford it
             forms += ['agpipe4'] if feat.size(1) >= 256 else []                   # four slabs of >= 64 columns
         if self._needed_ok(adj_parts, stages, group) and NeededRows.fraction_needed(adj_parts, group) < 0.75:
-            forms += ['needed', 'needed_a2a'] + (['needed_a2a2'] if feat.size(1) >= 64 else [])
+            # The staged point-to-point form (batch_isend_irecv per stage) has only ever run over gloo; over RCCL
+            # it is a candidate only on request (DGNN_AUTO_P2P=1). The all-to-all forms are plain collectives.
+            p2p = dist.get_backend(group) != 'nccl' or os.environ.get('DGNN_AUTO_P2P', '0') == '1'
+            forms += (['needed'] if p2p else []) + ['needed_a2a'] + (['needed_a2a2'] if feat.size(1) >= 64 else [])
         moved = (self.rows_moved, self.rows_full)
 
         def once(form):
@@ -569,15 +613,42 @@ class StagePipeline:
                 torch.cuda.synchronize(feat.device)
             return time.perf_counter() - t0
 
+        # the vote travels as a host tensor under gloo (its CUDA path stages through the host anyway)
+        vote_dev = feat.device if dist.get_backend(group) == 'nccl' else 'cpu'
+        log = DistEnv.env.logger.log
+
+        def trial(form):
+            """One run of a form on every rank -> the slowest rank's seconds, or None when it raised on any rank
+            (every rank learns the outcome from one MAX all-reduce, so all drop the same forms). 'bcast' is the
+            reference's own form and the fallback of all others: its failure is the job's."""
+            try:
+                t, bad = once(form), 0.0
+            except Exception as e:                          # noqa: BLE001 -- whatever it is, the form is out
+                if form == 'bcast':
+                    raise
+                log(f'pipeline auto {tag}: form {form} raised {type(e).__name__}: {e} -- dropped', rank=-1)
+                t, bad = 0.0, 1.0
+            v = torch.tensor([bad, t], dtype=torch.float64, device=vote_dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+            bad, t = (float(x) for x in v.tolist())
+            return None if bad else t
+
+        cap = float(os.environ.get('DGNN_AUTO_CAP_S', 30.0))
+        times = {}
         with torch.no_grad():
+            alive = []
             for f in forms:                                 # builds CSR blocks, plans and buffers: not timed
-                once(f)
-            # the vote travels as a host tensor under gloo (its CUDA path stages through the host anyway)
-            vote_dev = feat.device if dist.get_backend(group) == 'nccl' else 'cpu'
-            # best of two timed runs per form: one sample is at the mercy of whatever else the node is doing
-            t = torch.tensor([min(once(f), once(f)) for f in forms], dtype=torch.float64, device=vote_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        times = dict(zip(forms, (float(x) for x in t.tolist())))
+                t = trial(f)
+                if t is not None and (f == 'bcast' or t <= cap):
+                    alive.append(f)
+                elif t is not None:
+                    log(f'pipeline auto {tag}: form {f} took {t:.1f} s on first use (cap {cap:.0f} s) -- dropped', rank=0)
+            for f in alive:
+                # best of two timed runs per form: one sample is at the mercy of whatever else the node is doing
+                ts = [trial(f), trial(f)]
+                if None not in ts:
+                    times[f] = min(ts)
+        forms = [f for f in forms if f in times]
         form = min(forms, key=lambda f: (times[f], forms.index(f)))
         self.choice[key] = (form, times)
         self.rows_moved, self.rows_full = moved
@@ -617,6 +688,7 @@ class StagePipeline:
         group = env.world_group if group is None else group
         if stages is None:
             stages = [(j, j) for j in range(env.world_size)]
+        given = feat
         orig = feat.contiguous()
         # Collectives run on a view with its own version counter: a rooted broadcast "writes" its buffer on
         # the root too as far as autograd can tell (gloo's CUDA path really does), and this tensor is often
@@ -630,19 +702,20 @@ class StagePipeline:
                 spmm(adj_parts[stages[0][1]], feat, z, fresh=True)
             return z
 
+        # a temporary (the contiguous copy of a strided input) is gone after this call: never cached
         cacheable = (plain and self.cache_input and tag.startswith('Forward') and tag.endswith('L1')
-                     and not orig.requires_grad)
+                     and not orig.requires_grad and orig is given)
         if cacheable:
             hit = self._input_cache.get(tag)
-            if hit is not None and hit[0] == self._tensor_key(orig):
-                if 'gathered' in hit[1]:
+            if hit is not None and self._same_input(hit, orig):
+                if 'gathered' in hit[2]:
                     with timer.timing_cuda('spmm'):
-                        spmm(adj_parts.slab, hit[1]['gathered'][:, :feat.size(1)], z, fresh=True)
+                        spmm(adj_parts.slab, hit[2]['gathered'][:, :feat.size(1)], z, fresh=True)
                     return z
                 acc = _Sum(z)
                 for src, blk in stages:
                     with timer.timing_cuda('spmm'):
-                        acc.add(adj_parts[blk], feat if src == rank else hit[1][src])
+                        acc.add(adj_parts[blk], feat if src == rank else hit[2][src])
                 return acc.done()
         keep = {} if cacheable else None
 
@@ -665,7 +738,7 @@ class StagePipeline:
         else:
             self._run_bcast(adj_parts, feat, stages, group, z, keep, policy)
         if keep is not None:
-            self._input_cache[tag] = (self._tensor_key(orig), keep)
+            self._input_cache[tag] = (orig, orig._version, keep)
         return z
 
 

@@ -37,7 +37,8 @@ _p, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c
 
 class _CPlan(ctypes.Structure):          # struct dgnn_plan (include/dgnn_spmm.h)
     _fields_ = [('nstage', _i32), ('seg', _p), ('stage_seg_off', _p), ('cut', _p),
-                ('stage_cut_off', _p), ('npartial', _i64), ('max_seg_len', _i32), ('covers_rows', _i32)]
+                ('stage_cut_off', _p), ('npartial', _i64), ('max_seg_len', _i32), ('covers_rows', _i32),
+                ('hot_rows', _i32), ('hot_cols', _p), ('seg_hot', _p)]
 
 
 class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn_spmm.h)
@@ -69,7 +70,7 @@ for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_ABI = 210                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+_ABI = 225                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
 if _lib.dgnn_version() != _ABI:
     raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
                        'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')
@@ -321,10 +322,17 @@ class SegPlan:
     block's device; the result is deterministic for a given block, stage count and piece length.
     """
 
-    def __init__(self, A, nstage=1, piece_len=None):
+    def __init__(self, A, nstage=1, piece_len=None, hot_rows=0):
+        """``hot_rows`` = 256 or 512: a hot-tile plan (struct dgnn_plan, hot_* fields) -- per stage the hot_rows
+        most referenced columns of the column block are served from LDS; the plan then carries its own entry
+        arrays ``col`` / ``val`` (hot entries of every run first, column replaced by the tile slot)."""
         dev = A.device
         rp = A.rowptr.long()
         n, nnz = A.n, A.nnz
+        self.hot_rows = int(hot_rows) if nnz else 0
+        if self.hot_rows not in (0, 256, 512):
+            raise ValueError('hot_rows must be 0, 256 or 512')
+        self.col, self.val = A.col, A.val                     # the entry arrays this plan indexes
         if piece_len is None:
             piece_len = int(os.environ.get('DGNN_PIECE_LEN', 0)) or default_piece_len(A.nnz, nstage)
         if not 1 <= piece_len < 2 ** 31:
@@ -348,6 +356,30 @@ class SegPlan:
             k0 = torch.nonzero(first).flatten()
             k1 = torch.cat([k0[1:], torch.tensor([nnz], **i64)])
             run_row, run_cb = row_idx[k0], cb[k0]
+            run_hot = None
+            if self.hot_rows:
+                T = self.hot_rows
+                cnt = torch.bincount(A.col.long(), minlength=A.m)
+                cstage = torch.arange(A.m, **i64) // cbw
+                order = torch.argsort(cstage * (nnz + 1) + (nnz - cnt), stable=True)      # per stage, most referenced first
+                pos = torch.arange(A.m, **i64) - (cstage[order] * cbw)                     # rank inside the stage
+                take = (pos < T) & (cnt[order] > 0)
+                slot = torch.full((A.m,), -1, **i64)
+                slot[order[take]] = pos[take]
+                hot_cols = torch.zeros(nstage * T, **i64)
+                hot_cols[cstage[order[take]] * T + pos[take]] = order[take]
+                self.hot_cols = hot_cols.int().contiguous()
+                s_of = slot[A.col.long()]
+                is_hot = s_of >= 0
+                perm = torch.argsort(key * 2 + (~is_hot).long(), stable=True)              # inside a run: hot first, order kept
+                self.col = torch.where(is_hot, s_of, A.col.long())[perm].int().contiguous()
+                self.val = A.val[perm].contiguous()
+                self.perm = perm                                  # tests: entry order of the plan in terms of A's
+                hot_before = torch.cumsum(is_hot.long(), 0) - is_hot.long()                # exclusive, in CSR order
+                total_hot = torch.cat([hot_before, hot_before[-1:] + is_hot[-1:].long()])
+                run_hot = total_hot[k1] - total_hot[k0]           # hot entries of every run
+                self.hot_fraction = float(is_hot.sum().item()) / nnz
+                del cnt, cstage, order, pos, take, slot, s_of, is_hot, hot_before, total_hot
             del row_idx, cb, key, first
             pieces = (k1 - k0 + piece_len - 1) // piece_len
             is_cut = pieces > 1
@@ -358,6 +390,9 @@ class SegPlan:
             pk1 = torch.minimum(pk0 + piece_len, k1[run_of])
             prow, pcb, pcut = run_row[run_of], run_cb[run_of], is_cut[run_of]
             pout = torch.where(pcut, torch.cumsum(pcut.long(), 0) - 1, torch.full_like(pk0, -1))
+            pkh = None
+            if run_hot is not None:                               # where a piece's hot entries end
+                pkh = torch.minimum(torch.maximum((k0 + run_hot)[run_of], pk0), pk1)
             # rows with nothing in the first column block are listed there as empty runs: the first stage
             # then stores every row and a product that overwrites C needs no zero fill (covers_rows)
             has0 = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -368,8 +403,12 @@ class SegPlan:
                 prow, pk0, pk1 = torch.cat([prow, miss]), torch.cat([pk0, at]), torch.cat([pk1, at])
                 pcb = torch.cat([pcb, torch.zeros_like(miss)])
                 pout = torch.cat([pout, torch.full_like(miss, -1)])
+                if pkh is not None:
+                    pkh = torch.cat([pkh, at])
             order = torch.argsort(pcb * (piece_len + 1) + (piece_len - (pk1 - pk0)), stable=True)
             self.seg = torch.stack([prow, pk0, pk1, pout], dim=1)[order].int().contiguous()
+            if pkh is not None:
+                self.seg_hot = pkh[order].int().contiguous()
             self.stage_seg_off = torch.cat([torch.zeros(1, **i64), torch.cumsum(torch.bincount(pcb, minlength=nstage), 0)]).cpu().contiguous()
             cut_runs = torch.nonzero(is_cut).flatten()
             ccnt = pieces[cut_runs]
@@ -383,13 +422,19 @@ class SegPlan:
         self.ncut = self.cut.size(0)
         self.c = _CPlan(nstage, self.seg.data_ptr(), self.stage_seg_off.data_ptr(), self.cut.data_ptr(),
                         self.stage_cut_off.data_ptr(), self.npartial, int(piece_len), 1 if nnz else 0)
-        self._partial = None
+        if self.hot_rows:
+            self.c.hot_rows, self.c.hot_cols, self.c.seg_hot = self.hot_rows, self.hot_cols.data_ptr(), self.seg_hot.data_ptr()
+        self._partial = {}
 
     def partial(self, ldb, dev):
+        """Partial-row scratch of this plan, one buffer per stream (calls on one stream are ordered; two streams
+        aggregating with the same block must not share piece rows)."""
         need = max(self.npartial, 1) * ldb
-        if self._partial is None or self._partial.numel() < need:
-            self._partial = torch.empty(need, dtype=torch.float32, device=dev)
-        return self._partial
+        key = torch.cuda.current_stream(dev).cuda_stream
+        buf = self._partial.get(key)
+        if buf is None or buf.numel() < need:
+            buf = self._partial[key] = torch.empty(need, dtype=torch.float32, device=dev)
+        return buf
 
 
 class DevicePlan:
@@ -411,7 +456,7 @@ class DevicePlan:
             self.npartial = self.nseg = self.ncut = 0
             self.c = _CPlan(lay.nstage, self.ws.data_ptr(), self.stage_seg_off.data_ptr(), self.ws.data_ptr(),
                             self.stage_cut_off.data_ptr(), 0, lay.piece, 0)
-            self._partial = None
+            self._partial = {}
             return
         self.ws = torch.empty(lay.ws_ints, dtype=torch.int32, device=A.device)
         with torch.cuda.device(A.device):
@@ -426,7 +471,7 @@ class DevicePlan:
         self.c = _CPlan(lay.nstage, base + 4 * lay.hdr_ints, self.stage_seg_off.data_ptr(),
                         base + 4 * (lay.hdr_ints + 4 * lay.nstage * lay.nseg_max), self.stage_cut_off.data_ptr(),
                         self.npartial, lay.piece, 1)
-        self._partial = None
+        self._partial = {}
 
     def counts(self):
         """(segments, cut runs, partial rows) actually used -- reads the counters back (synchronises)."""
@@ -448,13 +493,20 @@ def _plan_for(A, F):
     dgnn_plan_build instead: no sorts over the nonzeros, no host synchronisation, a third of the set-up
     time -- what very large blocks want."""
     ns = default_stage_count(A.n, A.m, A.nnz, F)
+    # DGNN_HOT_ROWS=256|512 (opt-in, measured slower on every shape tried, DESIGN.md 3.1): hot-tile plans -- the
+    # B rows of each stage's most referenced columns staged in LDS. Only for blocks with enough work per stage.
+    hot = int(os.environ.get('DGNN_HOT_ROWS', 0) or 0)
+    if hot and A.nnz < (1 << 22):
+        hot = 0
     plans = A.__dict__.setdefault('_plans', {})
-    if ns not in plans:
-        if os.environ.get('DGNN_PLAN_BUILDER', 'torch') == 'device':
-            plans[ns] = DevicePlan(A, ns, None, F)
+    if (ns, hot) not in plans:
+        if hot:
+            plans[(ns, hot)] = SegPlan(A, ns, hot_rows=hot)
+        elif os.environ.get('DGNN_PLAN_BUILDER', 'torch') == 'device':
+            plans[(ns, hot)] = DevicePlan(A, ns, None, F)
         else:
-            plans[ns] = SegPlan(A, ns)
-    return plans[ns]
+            plans[(ns, hot)] = SegPlan(A, ns)
+    return plans[(ns, hot)]
 
 
 def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
@@ -472,7 +524,8 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
         plan = _plan_for(A, F)
     dev = C.device
     P = plan.partial(ldb, dev)
-    args = (ctypes.byref(plan.c), A.col.data_ptr(), A.val.data_ptr(), A.n, A.m, bptr, ldb, cptr, ldc,
+    col, val = getattr(plan, 'col', A.col), getattr(plan, 'val', A.val)      # a hot-tile plan indexes its own entry arrays
+    args = (ctypes.byref(plan.c), col.data_ptr(), val.data_ptr(), A.n, A.m, bptr, ldb, cptr, ldc,
             P.data_ptr(), ldb, F, float(alpha))
     if overwrite:
         fn = _lib.dgnn_spmm_plan_overwrite_f32

@@ -29,7 +29,7 @@ extern "C" {
 #define DGNN_E_HIP         2  /* a HIP runtime call or a kernel launch failed                 */
 #define DGNN_E_NODEVICE    3  /* no gfx950 device visible to this process                     */
 
-/* Library version: major*10000 + minor*100 + patch. */
+/* ABI version of this header: a plain counter (225 now); the Python stub refuses a library of another one. */
 int dgnn_version(void);
 
 /* Message for the last nonzero status returned on the calling thread ("" if none). */
@@ -132,6 +132,18 @@ typedef struct dgnn_plan {
   int64_t npartial;
   int32_t max_seg_len;      /* longest k1 - k0 in `seg` (> 0); bounds the critical path of a stage */
   int32_t covers_rows;
+  /* Hot-tile plans (hot_rows > 0; 0 = none, the three pointers are then ignored). Per stage the plan names the
+   * hot_rows most referenced columns of that column block; the kernel keeps their B rows (one feature chunk at a
+   * time) in LDS. Such a plan indexes its OWN copy of the entry arrays -- pass them as `col` / `val` -- in which
+   * every (row, stage) run lists its hot entries first, `col` holding the slot 0..hot_rows-1 instead of the column,
+   * then its other entries with their columns; both parts in ascending column order.
+   *   hot_rows   256 (feature chunks of 128 floats) or 512 (chunks of 64 floats)
+   *   hot_cols   device, int32[nstage * hot_rows]: column of every slot (unused slots: any valid column)
+   *   seg_hot    device, int32[nseg]: for segment i the position kh, k0 <= kh <= k1: entries [k0, kh) are hot
+   * An output element then sums, inside a stage, its hot nonzeros first and the others after them (one chain). */
+  int32_t hot_rows;
+  const int32_t* hot_cols;
+  const int32_t* seg_hot;
 } dgnn_plan;
 
 /*

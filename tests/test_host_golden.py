@@ -114,6 +114,7 @@ def test_per_rank_part_generation_equals_the_full_path(P):
         for k in ('labels', 'train_mask', 'val_mask', 'test_mask'):
             assert torch.equal(parts[r][k], mine[k]), k
         assert mine['features'].shape == parts[r]['features'].shape and mine['features'].dtype == torch.float32
+        assert torch.equal(mine['features'], parts[r]['features'])      # drawn per row tile: the same rows at any P
         assert mine['num_nodes'] == pre['num_nodes'] and mine['num_classes'] == pre['num_classes']
         import coo_graph
         g = coo_graph.Parted_COO_Graph('x', r, P, attr_dict=mine)      # loads like any part dict

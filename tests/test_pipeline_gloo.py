@@ -216,8 +216,11 @@ def _eight_worker(rank, world, port, log_dir, q):
         full = coo_graph.COO_Graph('odd', attr_dict=_odd_graph())
         g = coo_graph.Parted_COO_Graph('odd', rank, world, attr_dict=full.partition(world, save=False)[rank])
         res = {'rows': g.local_num_nodes}
-        for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2', 'auto'):
-            gcn._pipeline = gcn.StagePipeline(mode=mode, inflight=3, cache_input=False)
+        for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2', 'auto',
+                     'needed_a2a-blocks', 'needed_a2a2-blocks', 'allgather-blocks'):
+            gcn._pipeline = gcn.StagePipeline(mode=mode.split('-')[0], inflight=3, cache_input=False)
+            if mode.endswith('-blocks'):                      # P block products instead of the one fused slab product
+                gcn._pipeline.fused_slab = False
             res[mode] = gcn.broadcast(g.adj_parts, g.features, 'ForwardL1').numpy()
         gcn._pipeline = gcn.StagePipeline(mode='auto')
         res['losses'] = dist_train.train(g, env, total_epoch=3, hidden_dim=16, num_layers=3, eval_every=2)
@@ -267,7 +270,8 @@ def test_eight_ranks_every_form_equals_the_unpartitioned_product(tmp_path):
         assert 'error' not in res, res.get('error')
     s = out[0]['rows']
     assert s == 26
-    for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2', 'auto'):
+    for mode in ('bcast', 'allgather', 'agpipe', 'agpipe4', 'needed', 'needed_a2a', 'needed_a2a2', 'auto',
+                 'needed_a2a-blocks', 'needed_a2a2-blocks', 'allgather-blocks'):
         z = np.concatenate([out[r][mode] for r in range(world)])
         assert z.shape[0] == s * world and np.array_equal(z[:n], want), mode
         assert not z[n:].any()                                   # padding rows aggregate nothing

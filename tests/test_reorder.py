@@ -1,0 +1,70 @@
+"""Locality reordering (coo_graph/reorder.py, the mechanism of 1D_CAGNET/partition_torch_ready_data.py:15-57) is a
+pure relabelling: the permuted input gives the permuted answer. Checked with the CPU oracle (no GPU needed)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph(seed=4, n=157, e=900, f=9):
+    g = torch.Generator().manual_seed(seed)
+    return {"edge_index": torch.randint(0, n, (2, e), generator=g), "features": torch.rand(n, f, generator=g),
+            "labels": torch.randint(0, 5, (n,), generator=g), "train_mask": torch.rand(n, generator=g) < 0.5,
+            "val_mask": torch.zeros(n, dtype=torch.bool), "test_mask": torch.zeros(n, dtype=torch.bool),
+            "num_nodes": n, "num_edges": e, "num_classes": 5}
+
+
+@pytest.mark.parametrize('how', ['bfs', 'degree'])
+def test_reordering_is_a_pure_relabelling(how):
+    from coo_graph import reorder, graph_utils, parted_coo_graph
+    from oracle import ref_cpu
+    raw = _graph()
+    n = raw['num_nodes']
+    new = reorder.reorder_dataset(raw, how)
+    order = new['node_order']
+    assert torch.equal(torch.sort(order).values, torch.arange(n))
+    new_id = torch.empty(n, dtype=torch.long)
+    new_id[order] = torch.arange(n)
+    assert torch.equal(new['edge_index'], new_id[raw['edge_index']])          # same edges, relabelled
+    for k in ('features', 'labels', 'train_mask'):
+        assert torch.equal(new[k], raw[k][order])
+    a = graph_utils.preprocess('x', dict(raw), 'GCN')
+    b = graph_utils.preprocess('x', {k: v for k, v in new.items() if k != 'node_order'}, 'GCN')
+    A, Bm = a['adj'].coalesce(), b['adj'].coalesce()
+    # the normalised adjacency of the relabelled graph IS the relabelled normalised adjacency: indices exactly ...
+    want_idx, want_val = ref_cpu.coalesce(new_id[A.indices()].numpy(), A.values().numpy(), (n, n))
+    assert np.array_equal(Bm.indices().numpy(), want_idx)
+    np.testing.assert_allclose(Bm.values().numpy(), want_val, rtol=1e-6)      # ... values to rounding (degree sums reorder)
+    # ... and the aggregate of the relabelled input is the relabelled aggregate (north_star's 1e-5)
+    za = torch.sparse.mm(A, a['features'])
+    zb = torch.sparse.mm(Bm, b['features'])
+    assert float((zb - za[order]).abs().max()) <= 1e-5 * float(za.abs().max())
+    # the partition of the relabelled input: the package's split against the oracle's, bit for bit
+    for P in (2, 3):
+        _, parts = parted_coo_graph.partition_dict(dict(b), P)
+        s = -(-n // P)
+        for r, part in enumerate(parts):
+            sub = part['adj'].coalesce()
+            blocks = ref_cpu.sparse_2d_split(Bm.indices().numpy(), Bm.values().numpy(), (n, n), s, 0)
+            assert np.array_equal(sub.indices().numpy(), blocks[r][0])
+            assert np.array_equal(sub.values().numpy(), blocks[r][1])
+
+
+def test_bfs_order_puts_neighbours_close():
+    """A ring with scrambled ids: after the breadth-first relabelling every edge joins ids at most 2 apart."""
+    from coo_graph import reorder
+    n = 101
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+    ring = torch.stack([torch.arange(n), (torch.arange(n) + 1) % n])
+    raw = {"edge_index": perm[ring], "features": torch.zeros(n, 1), "labels": torch.zeros(n, dtype=torch.long),
+           "train_mask": torch.ones(n, dtype=torch.bool), "val_mask": torch.zeros(n, dtype=torch.bool),
+           "test_mask": torch.zeros(n, dtype=torch.bool), "num_nodes": n, "num_edges": n, "num_classes": 1}
+    assert int((raw['edge_index'][0] - raw['edge_index'][1]).abs().max()) > 50
+    new = reorder.reorder_dataset(raw, 'bfs')
+    assert int((new['edge_index'][0] - new['edge_index'][1]).abs().max()) <= 2
+    with pytest.raises(ValueError):
+        reorder.relabel(raw, torch.zeros(n, dtype=torch.long))

@@ -552,3 +552,166 @@ def test_full_size_reddit_shape_properties():
     exact = torch.sparse.mm(torch.sparse_coo_tensor(ci, adj.values().double(), (n, n)), B.double())
     for got in (Z, Zc):
         assert ((got.double() - exact).abs() <= 1e-5 * exact).all()
+
+
+_shape_blocks = {}
+
+
+def _shape_block(shape):
+    """The normalised adjacency of a BASELINE config's graph at FULL size as a CsrBlock (+ its COO), built once."""
+    import spmm_cpp
+    from coo_graph import synthetic, graph_utils
+    if shape not in _shape_blocks:
+        _shape_blocks.clear()                                     # one big graph resident at a time
+        torch.cuda.empty_cache()
+        dev = torch.device('cuda:0')
+        n = synthetic.SHAPES[shape][0]
+        d = synthetic.make_dataset(shape, seed=0, device=dev, with_features=False)
+        adj = graph_utils.sym_normalization(d['edge_index'], n)
+        del d
+        _shape_blocks[shape] = (spmm_cpp.CsrBlock.from_coo(adj), adj)
+    return _shape_blocks[shape]
+
+
+@pytest.mark.parametrize('shape,F', [('reddit', 602), ('reddit', 256), ('reddit', 41),
+                                     ('products', 100), ('products', 256), ('products', 47)])
+def test_full_size_configs_at_their_own_widths(shape, F):
+    """BASELINE configs 1 and 2 at full size AND at the widths their layers aggregate (Reddit 602 / 256 / 41,
+    ogbn-products 100 / 256 / 47), through the resident-plan path the models run: bits of the strict row kernel on
+    every row the plan does not cut, the fp64 bound (1e-5 relative: all terms are positive) on every element, exact
+    linearity under a power-of-two scale, the same bits from run to run, nothing left unwritten by the overwriting
+    first stage."""
+    import spmm_cpp
+    A, adj = _shape_block(shape)
+    dev = torch.device('cuda:0')
+    n = A.n
+    assert A.nnz > (114_000_000 if shape == 'reddit' else 126_000_000)
+    g = torch.Generator(device=dev).manual_seed(F)
+    B = torch.rand(n, F, device=dev, generator=g)
+    Z = torch.full((n, F), float('nan'), device=dev)
+    spmm_cpp.aggregate(A, B, Z, overwrite=True)                    # what the first stage of an aggregation runs
+    assert torch.isfinite(Z).all()
+    plan = spmm_cpp._plan_for(A, F)
+    Zk = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_csr(A, B, Zk, 1.0, 0.0)                          # row kernel: the oracle's chain, element by element
+    cbw = -(-A.m // plan.nstage)
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (A.rowptr[1:] - A.rowptr[:-1]).long())
+    runs = torch.zeros(n * plan.nstage, dtype=torch.long, device=dev)
+    runs.index_add_(0, rows * plan.nstage + A.col.long() // cbw, torch.ones_like(rows))
+    del rows
+    uncut = runs.view(n, plan.nstage).amax(1) <= plan.piece_len
+    assert int(uncut.sum()) > 0.9 * n
+    assert torch.equal(Z[uncut], Zk[uncut])
+    exact = torch.sparse.mm(torch.sparse_coo_tensor(adj.indices(), adj.values().double(), (n, n)), B.double())
+    assert ((Z.double() - exact).abs() <= 1e-5 * exact).all()
+    del Zk
+    Z2 = torch.zeros(n, F, device=dev)
+    spmm_cpp.aggregate(A, B * 2.0, Z2, overwrite=True)
+    assert torch.equal(Z2, Z * 2.0)
+    spmm_cpp.aggregate(A, B, Z2, overwrite=True)
+    assert torch.equal(Z2, Z)
+    # accumulate on top (what the later stages of an aggregation do): every chain starts from Z instead of 0. Small
+    # terms added one by one to a large running value round more than a sum from 0 does -- in the reference's chain
+    # too -- so the yardstick is the strict chain (row kernel, beta = 1): its bits on uncut rows, and on the cut hub
+    # rows an error against fp64 no larger than the strict chain's own plus 1e-5.
+    spmm_cpp.aggregate(A, B, Z2)
+    Zk = Z.clone()
+    spmm_cpp.spmm_csr(A, B, Zk, 1.0, 1.0)
+    assert torch.equal(Z2[uncut], Zk[uncut])
+    assert ((Z2.double() - 2.0 * exact).abs() <= 2e-5 * exact + (Zk.double() - 2.0 * exact).abs()).all()
+    del exact, Zk
+    if (shape, F) in (('reddit', 41), ('products', 47)):
+        _shape_blocks.clear()
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('F', [128, 172, 256])
+def test_papers_shaped_rank_slab(F):
+    """BASELINE config 4's shape through the path an 8-rank job runs: ONE rank's part built on the device without the
+    whole graph (synthetic.make_partition, the degree of ogbn-papers100M at 1/28 of its size: 4 M nodes, 58 M entries),
+    its row slab multiplied against the gathered features in one SpMM (the all-gather form) and block by block (the
+    broadcast form) -- same bits, the row kernel's bits on uncut rows, the fp64 bound everywhere. Widths: input 128,
+    hidden 256, 172 classes."""
+    import coo_graph
+    import spmm_cpp
+    from coo_graph import synthetic
+    from models import gcn
+    dev = torch.device('cuda:0')
+    P, rank, n, e = 8, 3, 4_000_000, 29_000_000
+    key = ('papers-part', n)
+    if key not in _shape_blocks:
+        _shape_blocks.clear()
+        torch.cuda.empty_cache()
+        part = synthetic.make_partition('papers', rank, P, seed=0, device=dev, num_nodes=n, num_edges=e)
+        _shape_blocks[key] = coo_graph.Parted_COO_Graph('papers', rank, P, device=dev, attr_dict=part)
+    pg = _shape_blocks[key]
+    s = pg.local_num_nodes
+    assert s == n // P and len(pg.adj_parts) == P and pg.adj_parts.slab.size(1) == s * P
+    assert pg.num_classes == 172 and int(pg.local_labels.max()) > 127          # 172 classes do not fit the reference's labels.char()
+    g = torch.Generator(device=dev).manual_seed(F)
+    H = torch.rand(s * P, F, device=dev, generator=g)
+    z_slab = torch.full((s, F), float('nan'), device=dev)
+    gcn.spmm(pg.adj_parts.slab, H, z_slab, fresh=True)
+    z_blocks = torch.full((s, F), float('nan'), device=dev)
+    for src in range(P):
+        gcn.spmm(pg.adj_parts[src], H[src * s:(src + 1) * s], z_blocks, fresh=(src == 0))
+    slab = gcn._csr_block(pg.adj_parts.slab)
+    deg = slab.rowptr[1:] - slab.rowptr[:-1]
+    short = deg <= 128
+    assert int(short.sum()) > 0.95 * s and int((deg == 1).sum()) > 0          # isolated nodes: the self loop only, nothing in 7 of 8 blocks
+    zk = torch.zeros(s, F, device=dev)
+    spmm_cpp.spmm_csr(slab, H, zk, 1.0, 0.0)
+    assert torch.equal(z_slab[short], zk[short]) and torch.equal(z_blocks[short], zk[short])
+    A = pg.adj_parts.slab.coalesce()
+    exact = torch.sparse.mm(torch.sparse_coo_tensor(A.indices(), A.values().double(), A.shape), H.double())
+    for got in (z_slab, z_blocks):
+        assert ((got.double() - exact).abs() <= 1e-5 * exact).all()
+    if F == 256:
+        _shape_blocks.clear()
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece,hot,alpha,beta', [
+    (3000, 5000, 200000, 3, 256, 2, 512, 256, 1.0, 1.0), (2500, 4000, 150000, 2, 100, 3, 256, 512, 0.5, 2.0),
+    (1500, 9000, 120000, 2, 602, 4, 1024, 256, 1.0, 0.0), (4000, 1200, 90000, 0, 41, 1, 4096, 512, 1.0, 1.0),
+    (700, 700, 30000, 1, 64, 2, 64, 512, -1.0, 1.0)])
+def test_hot_tile_plan_matches_the_oracle_on_its_own_entry_order(n, m, nnz, hubs, F, nstage, piece, hot, alpha, beta):
+    """Hot-tile plans (north_star's 'feature tiles of H_j staged in LDS'; opt-in, DGNN_HOT_ROWS): per stage the most
+    referenced columns' B rows sit in LDS and every run sums its hot entries first. The chain of an output element is
+    therefore the plan's own entry order: the CPU oracle run on that order gives the kernel's bits for every row no
+    stage cuts; against the true ascending order the result agrees within the fp64 bound like any cut row."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(n + F + hot)
+    row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
+    # a popularity skew, so that the hot set matters: fold half of the columns onto a few
+    fold = rng.random(col.size) < 0.5
+    col = np.where(fold, col % 97, col).astype(np.int32)
+    key = np.unique(row.astype(np.int64) * m + col)                      # re-coalesce
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    val = rng.random(key.size, dtype=np.float32)
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if beta == 0.0:
+        C0[:] = np.nan
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    plan = spmm_cpp.SegPlan(blk, nstage, piece, hot_rows=hot)
+    assert plan.hot_rows == hot and 0.3 < plan.hot_fraction <= 1.0
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+    Cg = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, Cg, alpha, beta, plan)
+    got = Cg.cpu().numpy()
+    rowptr = ref_cpu.coo2csr(row, n)
+    want_true = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), alpha, beta)
+    _check(got, want_true, rowptr, col, val, B, np.nan_to_num(C0), alpha, beta)      # fp64 bound on every element
+    perm = plan.perm.cpu().numpy()
+    want_perm = ref_cpu.spmm_csr(rowptr, col[perm], val[perm], B, C0.copy(), alpha, beta)
+    cbw = -(-m // nstage)
+    runs = np.zeros((n, nstage), dtype=np.int64)
+    np.add.at(runs, (row, col // cbw), 1)
+    uncut = runs.max(axis=1) <= piece
+    assert uncut.sum() > n // 2 and np.array_equal(got[uncut], want_perm[uncut])
+    again = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, again, alpha, beta, plan)
+    assert torch.equal(again, Cg)

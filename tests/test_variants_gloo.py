@@ -146,7 +146,7 @@ def scenario_input_cache(env, rank, world, gold_dir):
     # the all-gather form with the fused slab SpMM keeps the gathered matrix instead of per-source blocks
     gcn._pipeline = gcn.StagePipeline(mode='allgather', cache_input=True)
     losses = dist_train.train(g, env, total_epoch=3, eval_every=0)
-    kept = gcn.pipeline()._input_cache['ForwardL1'][1]
+    kept = gcn.pipeline()._input_cache['ForwardL1'][2]
     res['allgather'] = dict(losses=losses, transfers=gcn.pipeline().transfers, fused='gathered' in kept)
     g.features.mul_(1.0)        # in-place write bumps the version counter: the cache must not be reused
     gcn._pipeline = gcn.StagePipeline(cache_input=True)
@@ -155,6 +155,20 @@ def scenario_input_cache(env, rank, world, gold_dir):
     g.features.add_(0.0)
     gcn.broadcast(g.adj_parts, g.features, 'ForwardL1')
     res['after_write'] = (a, gcn.pipeline().transfers)
+    # a NEW tensor of the same shape every epoch (dropout, noise, a replaced g.features): freed after the call, so
+    # the allocator may hand its address to the next one -- every one of them must be sent
+    gcn._pipeline = gcn.StagePipeline(cache_input=True)
+    for _ in range(3):
+        x = g.features + 0.0
+        z = gcn.broadcast(g.adj_parts, x, 'ForwardL1')
+        del x
+    res['fresh_each_time'] = gcn.pipeline().transfers
+    # ... and a strided input (its contiguous copy is a temporary) is never cached
+    gcn._pipeline = gcn.StagePipeline(cache_input=True)
+    wide = torch.cat([g.features, g.features], dim=1)
+    for _ in range(2):
+        gcn.broadcast(g.adj_parts, wide[:, :g.features.size(1)], 'ForwardL1')
+    res['strided'] = gcn.pipeline().transfers
     return res
 
 
@@ -319,3 +333,4 @@ def test_input_cache_is_lossless(tmp_path):
         assert res['allgather']['transfers'] == 2 * (3 * 6 - 2)
         a, b = res['after_write']
         assert a == 2 and b == 4                                         # a write to the features invalidates the cache
+        assert res['fresh_each_time'] == 6 and res['strided'] == 4      # new tensors / temporaries are always sent

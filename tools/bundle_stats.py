@@ -11,13 +11,13 @@ adj = graph_utils.sym_normalization(d['edge_index'], n)
 row, col = adj.indices()
 nnz = row.numel()
 deg = torch.bincount(row, minlength=n)
-for nstage in (1, 8):
+for nstage in (1, 4):
     cbw = -(-n // nstage)
     cb = col // cbw
     # per (row, stage) length
     key = row * nstage + cb
     seglen = torch.bincount(key, minlength=n * nstage).view(n, nstage)
-    for R in (2, 4, 8):
+    for R in (2, 4, 8, 16):
         tot_union, tot_sum, tot_good_union, tot_good_sum = 0, 0, 0, 0
         for s in range(nstage):
             order = torch.argsort(seglen[:, s], descending=True, stable=True)

@@ -22,11 +22,15 @@ def build_graph(shape, scale, seed, dev, reorder=None):
     t0 = time.time()
     d = synthetic.make_dataset(shape, seed=seed, device=dev, num_nodes=n, num_edges=e, with_features=False)
     ei = d['edge_index']
-    if reorder == 'degree':          # what a degree-sorted relabelling of the nodes at data-preparation time would give
-        deg = torch.bincount(ei[0], minlength=n) + torch.bincount(ei[1], minlength=n)
+    if reorder:                      # what `prepare_data.py --reorder ...` gives: the same graph, nodes relabelled
+        from coo_graph import reorder as _reorder
+        t1 = time.time()
+        order = _reorder.ORDERS[reorder](ei, n)
         new_id = torch.empty(n, dtype=torch.long, device=dev)
-        new_id[torch.argsort(deg, descending=True, stable=True)] = torch.arange(n, device=dev)
+        new_id[order] = torch.arange(n, device=dev)
         ei = new_id[ei]
+        torch.cuda.synchronize()
+        print(f'# reorder {reorder}: {time.time()-t1:.2f}s', flush=True)
     adj = graph_utils.sym_normalization(ei, n)
     del d
     A = spmm_cpp.CsrBlock.from_coo(adj)
@@ -62,7 +66,7 @@ def main():
     ap.add_argument('--builder', default='torch', choices=['torch', 'device'], help='who builds the work plans')
     ap.add_argument('--drop-in', action='store_true', help='also time the reference-signature call spmm_cusparse(row, col, val, ...)')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
-    ap.add_argument('--reorder', default=None, choices=['degree'], help='relabel the nodes by descending degree first')
+    ap.add_argument('--reorder', default=None, choices=['degree', 'bfs'], help='relabel the nodes first (coo_graph/reorder.py)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     A, adj = build_graph(args.shape, args.scale, 0, dev, args.reorder)

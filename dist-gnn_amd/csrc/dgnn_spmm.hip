@@ -982,11 +982,43 @@ int launch_hot(int vwc, bool wide, const int4* seg, const int32_t* seg_hot, int3
   return DGNN_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Scratch of the no-allocation entry point (dgnn_spmm_coo_noalloc_f32): row pointer, device-built work plan
+// and partial rows of ONE call live in this file-scope array instead of caller workspaces. Every GPU the
+// library runs on holds its own copy (at its own address) until the process ends. In host code the array's
+// name is only a handle: the device address comes from hipGetSymbolAddress, once per device, and that pointer
+// is what kernels, memsets and size checks use.
+// ---------------------------------------------------------------------------------------
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)DGNN_NOALLOC_SCRATCH_BYTES;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+}  // namespace (interrupted: a __device__ array wants external or static linkage, not a namespace-scope anonymous one)
+
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+namespace {
+void* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Device address of `scratch` on the current device (looked up on the first call there).
+int noalloc_scratch(unsigned char** out) {
+  int dev = -1;
+  DGNN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(DGNN_E_BADARG, "noalloc: device index out of range%s (%lld)", "", dev);
+  void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!p) {
+    DGNN_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(DGNN_E_HIP, "noalloc: hipGetSymbolAddress returned a null address%s", "");
+    __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);      // every thread finds the same address
+  }
+  *out = static_cast<unsigned char*>(p);
+  return DGNN_OK;
+}
+
+size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 }  // namespace
 
 extern "C" {
 
-int dgnn_version(void) { return 225; }   // 225: dgnn_plan.hot_rows / hot_cols / seg_hot (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
+int dgnn_version(void) { return 230; }   // 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 
@@ -1168,6 +1200,47 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
   plan.npartial = d.npartial_max; plan.max_seg_len = d.piece; plan.covers_rows = 1;
   plan.hot_rows = 0; plan.hot_cols = nullptr; plan.seg_hot = nullptr;
   return dgnn_spmm_plan_f32(&plan, col, val, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, beta, stream);
+}
+
+int dgnn_noalloc_limits(int64_t* scratch_bytes) {
+  if (!scratch_bytes) return fail(DGNN_E_BADARG, "noalloc_limits: null pointer%s", "");
+  *scratch_bytes = (int64_t)NOALLOC_SCRATCH_BYTES;
+  return DGNN_OK;
+}
+
+int dgnn_noalloc_scratch_needed(int32_t n, int32_t m, int64_t nnz, int64_t ldb, int64_t* bytes) {
+  if (n < 0 || m < 0 || nnz < 0 || ldb < 0 || !bytes) return fail(DGNN_E_BADARG, "noalloc_scratch_needed: bad argument%s", "");
+  const dgnn_plan_layout d = device_plan_layout(n, m, nnz, ldb, 0, 0);
+  *bytes = (int64_t)(round256(((size_t)n + 1) * 4) + round256((size_t)d.ws_ints * 4) + round256((size_t)d.npartial_max * (size_t)ldb * 4));
+  return DGNN_OK;
+}
+
+int dgnn_spmm_coo_noalloc_f32(const int32_t* row, const int32_t* col, const float* val,
+                              int32_t n, int32_t m, int64_t nnz,
+                              const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                              float alpha, float beta, void* stream) {
+  if (n < 0 || m < 0 || F < 0 || nnz < 0 || nnz > 0x7fffffffLL)
+    return fail(DGNN_E_BADARG, "spmm_coo_noalloc: bad sizes%s (nnz=%lld)", "", nnz);
+  if (n == 0 || F == 0) return DGNN_OK;
+  if (ldb < F || ldb % 4 != 0 || !aligned(B, 16))
+    return fail(DGNN_E_BADARG, "spmm_coo_noalloc: B needs ldb >= F, ldb %% 4 == 0 and a 16-byte aligned base (dgnn_pad_rows_f32)%s", "");
+  int64_t need = 0;
+  int rc = dgnn_noalloc_scratch_needed(n, m, nnz, ldb, &need);
+  if (rc != DGNN_OK) return rc;
+  if ((size_t)need > NOALLOC_SCRATCH_BYTES)
+    return fail(DGNN_E_BADARG, "spmm_coo_noalloc: this block needs %s%lld bytes of scratch, the library holds "
+                "DGNN_NOALLOC_SCRATCH_BYTES (see dgnn_noalloc_limits); use dgnn_spmm_coo_aligned_f32 with caller workspaces", "", need);
+  unsigned char* base = nullptr;
+  rc = noalloc_scratch(&base);
+  if (rc != DGNN_OK) return rc;
+  const dgnn_plan_layout d = device_plan_layout(n, m, nnz, ldb, 0, 0);
+  int32_t* const rowptr_ws = reinterpret_cast<int32_t*>(base);
+  int32_t* const plan_ws = reinterpret_cast<int32_t*>(base + round256(((size_t)n + 1) * 4));
+  float* const partial = reinterpret_cast<float*>(base + round256(((size_t)n + 1) * 4) + round256((size_t)d.ws_ints * 4));
+  // every word the kernels read is written first by this call (coo2csr fills the row pointer, dgnn_plan_build
+  // clears the counters and marks every list slot dead, partial rows are stored before the merge reads them),
+  // so what the previous call left in the array does not matter
+  return dgnn_spmm_coo_aligned_f32(row, col, val, n, m, nnz, rowptr_ws, plan_ws, B, ldb, C, ldc, partial, ldb, F, alpha, beta, stream);
 }
 
 static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float* val,

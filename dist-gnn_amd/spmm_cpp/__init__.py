@@ -61,6 +61,9 @@ _SIGNATURES = {                          # argument types, in the order of inclu
     'dgnn_spmm_coo_f32': [_p, _p, _p, _i32, _i32, _i64, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
     'dgnn_coo_aligned_workspace': [_i32, _i32, _i64, _i64, _pi64, _pi64],
     'dgnn_spmm_coo_aligned_f32': [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+    'dgnn_noalloc_limits': [_pi64],
+    'dgnn_noalloc_scratch_needed': [_i32, _i32, _i64, _i64, _pi64],
+    'dgnn_spmm_coo_noalloc_f32': [_p, _p, _p, _i32, _i32, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
     'dgnn_plan_layout_for': [_i32, _i32, _i64, _i64, _i32, _i32, ctypes.POINTER(_CLayout)],
     'dgnn_plan_build': [_p, _p, _i32, _i32, ctypes.POINTER(_CLayout), _p, _p],
     'dgnn_spmm_plan_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
@@ -70,7 +73,7 @@ for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_ABI = 225                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+_ABI = 230                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
 if _lib.dgnn_version() != _ABI:
     raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
                        'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')

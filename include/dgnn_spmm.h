@@ -29,7 +29,7 @@ extern "C" {
 #define DGNN_E_HIP         2  /* a HIP runtime call or a kernel launch failed                 */
 #define DGNN_E_NODEVICE    3  /* no gfx950 device visible to this process                     */
 
-/* ABI version of this header: a plain counter (225 now); the Python stub refuses a library of another one. */
+/* ABI version of this header: a plain counter (230 now); the Python stub refuses a library of another one. */
 int dgnn_version(void);
 
 /* Message for the last nonzero status returned on the calling thread ("" if none). */
@@ -219,6 +219,27 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
                               int32_t n, int32_t m, int64_t nnz, int32_t* rowptr_ws, int32_t* plan_ws,
                               const float* B, int64_t ldb, float* C, int64_t ldc,
                               float* partial, int64_t ldp, int32_t F,
+                              float alpha, float beta, void* stream);
+
+/*
+ * dgnn_spmm_coo_aligned_f32 for callers that cannot allocate or carry workspaces: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc. NO COUNTERPART IN THE REFERENCE. Same
+ * operands and results as dgnn_spmm_coo_aligned_f32 (same kernels), minus the three workspace arguments:
+ * row pointer, device-built work plan and partial rows live in a file-scope device array of
+ * DGNN_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends. The call
+ * allocates and frees nothing and does not synchronise.
+ *   limit     dgnn_noalloc_scratch_needed(n, m, nnz, ldb) <= DGNN_NOALLOC_SCRATCH_BYTES, else DGNN_E_BADARG
+ *             (roughly: up to ~1 M rows, any nnz < 2^31, at 256-float rows; dgnn_noalloc_limits reports the size)
+ *   sharing   all calls on one GPU use that GPU's one array: calls that overlap in time on one GPU (two
+ *             streams, two threads, a graph replay next to an eager call) RACE. Serialise them.
+ *   B         ldb >= F, ldb % 4 == 0, 16-byte aligned base, as for dgnn_spmm_coo_aligned_f32
+ */
+#define DGNN_NOALLOC_SCRATCH_BYTES (64u << 20)
+int dgnn_noalloc_limits(int64_t* scratch_bytes);
+int dgnn_noalloc_scratch_needed(int32_t n, int32_t m, int64_t nnz, int64_t ldb, int64_t* bytes);
+int dgnn_spmm_coo_noalloc_f32(const int32_t* row, const int32_t* col, const float* val,
+                              int32_t n, int32_t m, int64_t nnz,
+                              const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
                               float alpha, float beta, void* stream);
 
 /*

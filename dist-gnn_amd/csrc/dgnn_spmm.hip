@@ -598,6 +598,160 @@ __global__ __launch_bounds__(HOT_WAVES * 64) void spmm_hot_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Row bundles: register reuse across rows that share columns.
+//
+// The stage kernel pays one gather of a B-row slice per nonzero, and the unit that serves gathers is what bounds
+// it. Rows of similar length share many columns on graphs with hub columns, so the plan may tie R rows (R = 4 or
+// 8, consecutive in the longest-first order of a stage) into a bundle: the union of their columns is walked once,
+// each gathered slice is multiplied into up to R accumulators. Per union entry the plan stores the column and R
+// values (0 where the row has no such nonzero: fma(0, b, acc) leaves acc as it is for finite b, so every row still
+// sees exactly its own nonzeros in ascending column order -- the chain, and the bits, of the stage kernel).
+//   desc   int32[(R + 4) * ndesc]: {row_0 .. row_(R-1) (-1: none), k0, k1, out, 0} per bundle piece, longest first;
+//          out < 0: the rows accumulate into C; else piece sums go to partial rows out + r (merged per row afterwards)
+//   ucol   int32[nu] union columns, uval float[nu * R] values, entry k at uval[k * R + r]
+// ---------------------------------------------------------------------------------------
+template <int R, int L, int U, int VWC, bool WIDE>
+__global__ __launch_bounds__(256) void spmm_bundle_kernel(
+    const int32_t* __restrict__ desc, int32_t ndesc, uint32_t nsegblocks,
+    const int32_t* __restrict__ ucol, const float* __restrict__ uval,
+    const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+    float* __restrict__ P, int64_t ldp, int32_t F, float alpha, uint32_t k, int fresh) {
+  constexpr int G = 64 / L;
+  constexpr int SEGM = (R == 4 ? 128 : 64) * L / 16;          // strip entries per lane group
+  constexpr int PER = SEGM / L;                              // entries a lane loads per strip
+  constexpr int DW = R + 4;
+  __shared__ uint32_t off_all[4][G][SEGM];
+  __shared__ float4 val_all[4][G][SEGM * R / 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L;
+  const int li = lane % L;
+  uint32_t* const off = off_all[wave][g];
+  float4* const vals = val_all[wave][g];
+
+  const uint32_t nb = gridDim.x, b = blockIdx.x;
+  const uint32_t q = nb >> 3, xcd = b & 7;                   // nb % 8 == 0 (launcher)
+  const uint32_t w = xcd * q + (b >> 3);
+  const uint32_t chunk = w / nsegblocks;
+  const uint32_t p = w - chunk * nsegblocks;
+  uint32_t sb = p;
+  if (k > 1) {
+    const uint32_t qc = nsegblocks / k;
+    const uint32_t v0 = xcd * q, c0 = chunk * nsegblocks;
+    const uint32_t lo = (v0 > c0 ? v0 - c0 : 0u);
+    const uint32_t hi = min(v0 + q - c0, nsegblocks);
+    const uint32_t j0 = lo / qc, ncl = hi / qc - j0;
+    const uint32_t t = p - lo;
+    sb = (t / ncl) * k + j0 + t % ncl;
+  }
+  const int64_t didx = ((int64_t)sb * 4 + wave) * G + g;
+  const int fbase = (chunk * L + li) * 4;
+  const bool gathers = fbase < (int)ldb;
+  const uint32_t loff = (uint32_t)fbase * 4u;
+  const uint32_t ldb_bytes = (uint32_t)ldb * 4u;
+  const char* const Bbytes = reinterpret_cast<const char*>(B);
+
+  int rows[R];
+  int kb = 0, ke = 0, out = -1;
+#pragma unroll
+  for (int r = 0; r < R; ++r) rows[r] = -1;
+  if (didx < ndesc) {
+    const int32_t* d = desc + didx * DW;
+#pragma unroll
+    for (int r = 0; r < R; ++r) rows[r] = d[r];
+    kb = d[R]; ke = d[R + 1]; out = d[R + 2];
+  }
+  const bool direct = out < 0;
+  f32x2 a01[R], a23[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    a01[r] = {0.f, 0.f}; a23[r] = {0.f, 0.f};
+    if (rows[r] >= 0 && direct && !fresh) c_load<VWC>(C + (int64_t)rows[r] * ldc + fbase, fbase, F, a01[r], a23[r]);
+  }
+
+#pragma unroll 1
+  for (int sb0 = kb; sb0 < ke; sb0 += SEGM) {
+    const int se = min(sb0 + SEGM, ke);
+    const int len = se - sb0;
+#pragma unroll 1
+    for (int t = 0; t < PER && t * L < len; ++t) {
+      const int kk = min(sb0 + li + t * L, se - 1);
+      const uint32_t c1 = (uint32_t)ucol[kk];
+      float4 v[R / 4];
+#pragma unroll
+      for (int h = 0; h < R / 4; ++h) v[h] = *reinterpret_cast<const float4*>(uval + (int64_t)kk * R + 4 * h);
+      off[li + t * L] = WIDE ? c1 : c1 * ldb_bytes;
+#pragma unroll
+      for (int h = 0; h < R / 4; ++h)
+        vals[(li + t * L) * (R / 4) + h] = make_float4(alpha * v[h].x, alpha * v[h].y, alpha * v[h].z, alpha * v[h].w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (gathers) {
+      int j = 0;
+#pragma unroll 1
+      for (; j + U <= len; j += U) {
+        uint32_t o[U];
+        float4 bb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) o[u] = off[j + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if constexpr (WIDE) bb[u] = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)o[u] * ldb_bytes + loff));
+          else bb[u] = *reinterpret_cast<const float4*>(Bbytes + (o[u] + loff));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int h = 0; h < R / 4; ++h) {
+            const float4 v = vals[(j + u) * (R / 4) + h];
+            const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 vv = {vr[e], vr[e]};
+              a01[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01[4 * h + e]);
+              a23[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23[4 * h + e]);
+            }
+          }
+        }
+      }
+#pragma unroll 1
+      for (; j < len; ++j) {
+        const uint32_t o = off[j];
+        float4 bb;
+        if constexpr (WIDE) bb = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)o * ldb_bytes + loff));
+        else bb = *reinterpret_cast<const float4*>(Bbytes + (o + loff));
+#pragma unroll
+        for (int h = 0; h < R / 4; ++h) {
+          const float4 v = vals[j * (R / 4) + h];
+          const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 vv = {vr[e], vr[e]};
+            a01[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb.x, bb.y}, a01[4 * h + e]);
+            a23[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb.z, bb.w}, a23[4 * h + e]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (rows[r] < 0) continue;
+    if (!direct) {
+      if (fbase < ldp) *reinterpret_cast<float4*>(P + (int64_t)(out + r) * ldp + fbase) = make_float4(a01[r].x, a01[r].y, a23[r].x, a23[r].y);
+    } else if (ke > kb || fresh) {
+      c_store<VWC>(C + (int64_t)rows[r] * ldc + fbase, fbase, F, a01[r], a23[r]);
+    }
+  }
+}
+
 // C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order). One wave per cut run; a lane owns
 // float4 columns of the (16-B aligned, padded) partial rows and keeps 4 piece loads in flight.
 template <int VWC>
@@ -606,9 +760,10 @@ __global__ __launch_bounds__(256) void merge_kernel(
     float* __restrict__ C, int64_t ldc, int32_t F, int fresh) {
   const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (run >= ncut) return;
-  const int4 c4 = cut[run];                    // {row, pbase, count, -}
+  const int4 c4 = cut[run];                    // {row, pbase, count, piece stride - 1}
   if (c4.z <= 0) return;                        // unused slot (list sized by an upper bound)
   const int lane = threadIdx.x & 63;
+  const int64_t pst = (int64_t)(c4.w + 1) * ldp;   // partial rows of consecutive pieces are c4.w + 1 apart (row bundles: R)
   for (int f = lane * 4; f < F; f += 256) {
     float* c = C + (int64_t)c4.x * ldc + f;
     f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
@@ -618,12 +773,12 @@ __global__ __launch_bounds__(256) void merge_kernel(
     for (; s + 4 <= c4.z; s += 4) {
       float4 t[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(p + (int64_t)(s + u) * ldp);
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(p + (int64_t)(s + u) * pst);
 #pragma unroll
       for (int u = 0; u < 4; ++u) { a01.x += t[u].x; a01.y += t[u].y; a23.x += t[u].z; a23.y += t[u].w; }
     }
     for (; s < c4.z; ++s) {
-      const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * ldp);
+      const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * pst);
       a01.x += t.x; a01.y += t.y; a23.x += t.z; a23.y += t.w;
     }
     c_store<VWC>(c, f, F, a01, a23);
@@ -982,6 +1137,31 @@ int launch_hot(int vwc, bool wide, const int4* seg, const int32_t* seg_hot, int3
   return DGNN_OK;
 }
 
+
+template <int R, int L, int U>
+int launch_bundle(int vwc, bool wide, const int32_t* desc, int32_t ndesc, const int32_t* ucol, const float* uval,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, float* P, int64_t ldp,
+                  int32_t F, float alpha, bool fresh, hipStream_t s) {
+  constexpr int G = 64 / L;
+  int64_t nsegblocks = ((int64_t)ndesc + 4 * G - 1) / (4 * G);
+  const int64_t nchunks = (ldb / 4 + L - 1) / L;
+  int64_t gcd8 = 8;
+  while (nchunks % gcd8) gcd8 >>= 1;
+  const uint32_t k = (uint32_t)(8 / gcd8);
+  nsegblocks = (nsegblocks + k - 1) / k * k;
+  const int64_t nb = nsegblocks * nchunks;
+  if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "bundle grid out of range%s (%lld)", "", nb);
+  ProfScope prof(s, 0);
+#define DGNN_BUNDLE(VWC, WIDE)                                                                                 \
+  hipLaunchKernelGGL((spmm_bundle_kernel<R, L, U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, desc, ndesc, \
+                     (uint32_t)nsegblocks, ucol, uval, B, ldb, C, ldc, P, ldp, F, alpha, k, fresh ? 1 : 0)
+  if (wide) { if (vwc == 4) DGNN_BUNDLE(4, true); else if (vwc == 2) DGNN_BUNDLE(2, true); else DGNN_BUNDLE(1, true); }
+  else { if (vwc == 4) DGNN_BUNDLE(4, false); else if (vwc == 2) DGNN_BUNDLE(2, false); else DGNN_BUNDLE(1, false); }
+#undef DGNN_BUNDLE
+  DGNN_HIP(hipGetLastError());
+  return DGNN_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // Scratch of the no-allocation entry point (dgnn_spmm_coo_noalloc_f32): row pointer, device-built work plan
 // and partial rows of ONE call live in this file-scope array instead of caller workspaces. Every GPU the
@@ -1018,7 +1198,7 @@ size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" {
 
-int dgnn_version(void) { return 230; }   // 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
+int dgnn_version(void) { return 240; }   // 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 
@@ -1241,6 +1421,68 @@ int dgnn_spmm_coo_noalloc_f32(const int32_t* row, const int32_t* col, const floa
   // clears the counters and marks every list slot dead, partial rows are stored before the merge reads them),
   // so what the previous call left in the array does not matter
   return dgnn_spmm_coo_aligned_f32(row, col, val, n, m, nnz, rowptr_ws, plan_ws, B, ldb, C, ldc, partial, ldb, F, alpha, beta, stream);
+}
+
+int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                         int32_t F, float alpha, float beta, void* stream) {
+  if (!plan) return fail(DGNN_E_BADARG, "spmm_bundle: null plan%s", "");
+  const int R = plan->rows_per_bundle;
+  if (R != 4 && R != 8) return fail(DGNN_E_BADARG, "spmm_bundle: rows_per_bundle must be 4 or 8%s", "");
+  if (n < 0 || m < 0 || F < 0 || plan->nstage < 0) return fail(DGNN_E_BADARG, "spmm_bundle: negative size%s", "");
+  if (n == 0 || F == 0) return DGNN_OK;
+  if (!C || ldc < F) return fail(DGNN_E_BADARG, "spmm_bundle: bad C%s", "");
+  hipStream_t s = (hipStream_t)stream;
+  const bool empty = plan->nstage == 0 || !plan->stage_desc_off || plan->stage_desc_off[plan->nstage] == 0;
+  // the first stage lists every row of the block (rows with nothing there in bundles of their own kind), so a
+  // product with beta == 0 overwrites C without a zero fill and without reading it
+  const bool overwrite = beta == 0.f && !empty && plan->stage_desc_off[1] > plan->stage_desc_off[0];
+  if (beta != 1.f && !overwrite) {
+    ProfScope prof(s, 1);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(capped_blocks((int64_t)n * F, 8192)), dim3(256), 0, s, C, ldc, n, F, beta);
+    DGNN_HIP(hipGetLastError());
+  }
+  if (empty) return DGNN_OK;
+  if (!plan->desc || !plan->ucol || !plan->uval || !plan->stage_cut_off || !B)
+    return fail(DGNN_E_BADARG, "spmm_bundle: null pointer%s", "");
+  if (ldb < F || ldb % 4 != 0 || !aligned(B, 16) || !aligned(plan->uval, 16))
+    return fail(DGNN_E_BADARG, "spmm_bundle: B needs ldb >= F, ldb %% 4 == 0 and a 16-byte aligned base; uval 16-byte aligned%s", "");
+  const int64_t ncut_all = plan->stage_cut_off[plan->nstage];
+  if (ncut_all > 0 && (!partial || !plan->cut || ldp < ldb || ldp % 4 != 0 || !aligned(partial, 16)))
+    return fail(DGNN_E_BADARG, "spmm_bundle: cut bundles need a 16-byte aligned partial buffer with ldp >= ldb, ldp %% 4 == 0%s", "");
+  if (overlap(B, m, ldb, C, n, ldc, F)) return fail(DGNN_E_BADARG, "spmm_bundle: B and C overlap%s", "");
+  const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : ((ldc % 2 == 0 && aligned(C, 8)) ? 2 : 1);
+  const bool wide = ((uint64_t)(m > 0 ? m : 1) * (uint64_t)ldb * 4u) >= 0xffffff00ull;
+  const bool wg = ldb >= 256 && g_variant != 16;              // 512-byte slices from 256 floats up, as in the stage kernel
+  const int u = (g_variant >= 102 && g_variant <= 108) ? g_variant - 100 : 4;
+  bool fresh = overwrite;
+  for (int32_t st = 0; st < plan->nstage; ++st) {
+    const int64_t d0 = plan->stage_desc_off[st], d1 = plan->stage_desc_off[st + 1];
+    if (d1 > d0) {
+      const int32_t* desc = plan->desc + d0 * (R + 4);
+      const int32_t ndesc = (int32_t)(d1 - d0);
+      int rc;
+#define DGNN_LB(RR, LL, UU) launch_bundle<RR, LL, UU>(vwc, wide, desc, ndesc, plan->ucol, plan->uval, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s)
+      if (R == 4) rc = wg ? (u == 2 ? DGNN_LB(4, 32, 2) : u == 8 ? DGNN_LB(4, 32, 8) : DGNN_LB(4, 32, 4))
+                          : (u == 2 ? DGNN_LB(4, 16, 2) : u == 8 ? DGNN_LB(4, 16, 8) : DGNN_LB(4, 16, 4));
+      else rc = wg ? (u == 2 ? DGNN_LB(8, 32, 2) : DGNN_LB(8, 32, 4)) : (u == 2 ? DGNN_LB(8, 16, 2) : DGNN_LB(8, 16, 4));
+#undef DGNN_LB
+      if (rc != DGNN_OK) return rc;
+    }
+    const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
+    if (p1 > p0) {
+      ProfScope prof(s, 1);
+      const int32_t nc = (int32_t)(p1 - p0);
+      const dim3 grid((unsigned)((nc + 3) / 4));
+      const int4* cutp = reinterpret_cast<const int4*>(plan->cut) + p0;
+      if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
+      else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
+      else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
+      DGNN_HIP(hipGetLastError());
+    }
+    if (d1 > d0 || p1 > p0) fresh = false;
+  }
+  return DGNN_OK;
 }
 
 static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float* val,

@@ -41,6 +41,11 @@ class _CPlan(ctypes.Structure):          # struct dgnn_plan (include/dgnn_spmm.h
                 ('hot_rows', _i32), ('hot_cols', _p), ('seg_hot', _p)]
 
 
+class _CBundlePlan(ctypes.Structure):    # struct dgnn_bundle_plan (include/dgnn_spmm.h)
+    _fields_ = [('nstage', _i32), ('rows_per_bundle', _i32), ('desc', _p), ('stage_desc_off', _p), ('ucol', _p), ('uval', _p),
+                ('cut', _p), ('stage_cut_off', _p), ('npartial', _i64)]
+
+
 class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn_spmm.h)
     _fields_ = [('nstage', _i32), ('piece', _i32), ('hdr_ints', _i64), ('nseg_max', _i64), ('ncut_max', _i64),
                 ('npartial_max', _i64), ('ws_ints', _i64)]
@@ -67,13 +72,14 @@ _SIGNATURES = {                          # argument types, in the order of inclu
     'dgnn_plan_layout_for': [_i32, _i32, _i64, _i64, _i32, _i32, ctypes.POINTER(_CLayout)],
     'dgnn_plan_build': [_p, _p, _i32, _i32, ctypes.POINTER(_CLayout), _p, _p],
     'dgnn_spmm_plan_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+    'dgnn_spmm_bundle_f32': [ctypes.POINTER(_CBundlePlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
     'dgnn_spmm_plan_overwrite_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
 }
 for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_ABI = 230                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+_ABI = 240                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
 if _lib.dgnn_version() != _ABI:
     raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
                        'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')
@@ -332,6 +338,7 @@ class SegPlan:
         dev = A.device
         rp = A.rowptr.long()
         n, nnz = A.n, A.nnz
+        self.n = n
         self.hot_rows = int(hot_rows) if nnz else 0
         if self.hot_rows not in (0, 256, 512):
             raise ValueError('hot_rows must be 0, 256 or 512')
@@ -502,14 +509,58 @@ def _plan_for(A, F):
     if hot and A.nnz < (1 << 22):
         hot = 0
     plans = A.__dict__.setdefault('_plans', {})
-    if (ns, hot) not in plans:
-        if hot:
-            plans[(ns, hot)] = SegPlan(A, ns, hot_rows=hot)
+    # Row bundles (BundlePlan): 4 rows share one gather per union column. Worth it where the rows of a block share
+    # many columns -- decided per block by building the plan once and reading its union ratio (gathers per nonzero;
+    # Reddit shape 0.74: -13..-20 % time; sparse shapes ~1: more index bytes for nothing) -- and only for feature
+    # blocks of at least 128 floats (narrower ones are not bound by the gathers). DGNN_BUNDLE=0 turns them off,
+    # DGNN_BUNDLE=1 forces them.
+    want = os.environ.get('DGNN_BUNDLE', 'auto')
+    bundle = (not hot and want != '0' and padded_width(F) >= 128 and A.nnz >= (1 << 16)
+              and os.environ.get('DGNN_PLAN_BUILDER', 'torch') != 'device')
+    if bundle and want != '1':
+        ok = A.__dict__.get('_bundle_ok')
+        if ok is None:                                          # one cheap test per block: distinct (row pair, column)
+            ok = A.__dict__['_bundle_ok'] = _bundle_worth_it(A)
+        bundle = ok
+    key = (ns, hot, 'bundle' if bundle else 'runs')
+    if key not in plans:
+        if bundle:
+            plans[key] = BundlePlan(A, bundle_stage_count(A.n, A.m, A.nnz, F), 4)
+        elif hot:
+            plans[key] = SegPlan(A, ns, hot_rows=hot)
         elif os.environ.get('DGNN_PLAN_BUILDER', 'torch') == 'device':
-            plans[(ns, hot)] = DevicePlan(A, ns, None, F)
+            plans[key] = DevicePlan(A, ns, None, F)
         else:
-            plans[(ns, hot)] = SegPlan(A, ns)
-    return plans[(ns, hot)]
+            plans[key] = SegPlan(A, ns)
+    return plans[key]
+
+
+def bundle_stage_count(n, m, nnz, F):
+    """Column-block stages of a bundle plan: a bundle's run is the union of four rows' runs, so runs stay long with more
+    stages than default_stage_count allows (measured on the Reddit shape: 6 instead of 4 at 602 floats)."""
+    ld = padded_width(F)
+    if n == 0 or nnz == 0:
+        return 1
+    by_cache = -(-m * 256 // (10 << 20))
+    by_density = max(1, int(4 * nnz / max(n, 1) / 24))
+    return int(max(1, min(by_cache, by_density, 16)))
+
+
+def _bundle_worth_it(A, R=4, limit=0.85):
+    """True when tying R rows of similar length together cuts the gathers to at most ``limit`` of the nonzeros:
+    rows ranked by length, R consecutive ones a group, distinct (group, column) pairs counted (one stage)."""
+    if A.nnz == 0 or A.n < 2 * R:
+        return False
+    rp = A.rowptr.long()
+    deg = rp[1:] - rp[:-1]
+    if float(A.nnz) / A.n < 16:                                 # a few nonzeros per row: nothing to share
+        return False
+    order = torch.argsort(deg, descending=True, stable=True)
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(A.n, device=A.device)
+    grp = torch.repeat_interleave(rank // R, deg)
+    distinct = torch.unique(grp * A.m + A.col.long()).numel()
+    return distinct <= limit * A.nnz
 
 
 def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
@@ -527,13 +578,18 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
         plan = _plan_for(A, F)
     dev = C.device
     P = plan.partial(ldb, dev)
-    col, val = getattr(plan, 'col', A.col), getattr(plan, 'val', A.val)      # a hot-tile plan indexes its own entry arrays
-    args = (ctypes.byref(plan.c), col.data_ptr(), val.data_ptr(), A.n, A.m, bptr, ldb, cptr, ldc,
-            P.data_ptr(), ldb, F, float(alpha))
-    if overwrite:
-        fn = _lib.dgnn_spmm_plan_overwrite_f32
+    if isinstance(plan, BundlePlan):
+        fn = _lib.dgnn_spmm_bundle_f32
+        args = (ctypes.byref(plan.c), A.n, A.m, bptr, ldb, cptr, ldc, P.data_ptr(), ldb, F, float(alpha),
+                0.0 if overwrite else float(beta))
     else:
-        fn, args = _lib.dgnn_spmm_plan_f32, args + (float(beta),)
+        col, val = getattr(plan, 'col', A.col), getattr(plan, 'val', A.val)      # a hot-tile plan indexes its own entry arrays
+        args = (ctypes.byref(plan.c), col.data_ptr(), val.data_ptr(), A.n, A.m, bptr, ldb, cptr, ldc,
+                P.data_ptr(), ldb, F, float(alpha))
+        if overwrite:
+            fn = _lib.dgnn_spmm_plan_overwrite_f32
+        else:
+            fn, args = _lib.dgnn_spmm_plan_f32, args + (float(beta),)
     if torch.cuda.current_device() == dev.index:         # the usual case: no device switch to pay for
         rc = fn(*args, _stream(C))
     else:
@@ -568,3 +624,115 @@ def aggregate(A, H, Z, overwrite=False):
         with torch.cuda.device(H.device):
             H = pad_rows(H, _pad_buffer(H.size(0), padded_width(F), H.device))
     spmm_plan(A, H, Z, 1.0, 1.0, overwrite=overwrite)
+
+
+# --------------------------------------------------------------------------- row bundles (register reuse across rows)
+class BundlePlan:
+    """``struct dgnn_bundle_plan`` for one CsrBlock: R rows that share columns are multiplied together
+    (``spmm_bundle_kernel``). Per stage the rows are taken longest first, R at a time; a bundle walks the union of its
+    rows' columns once and every gathered slice of B feeds up to R accumulators. Per union entry: the column and R
+    values (0 where a row lacks it). Every row still sums its own nonzeros in ascending column order, so rows of uncut
+    bundles carry the strict chain's bits (``uncut_rows``). Integer work with torch ops on the block's device, once."""
+
+    def __init__(self, A, nstage=1, R=4, piece_len=None):
+        if R not in (4, 8):
+            raise ValueError('R must be 4 or 8')
+        dev = A.device
+        n, m, nnz = A.n, A.m, A.nnz
+        nstage = max(1, int(nstage))
+        if piece_len is None:
+            piece_len = int(os.environ.get('DGNN_PIECE_LEN', 0)) or default_piece_len(nnz, nstage)
+        self.nstage, self.R, self.piece_len = nstage, R, int(piece_len)
+        i64 = dict(dtype=torch.long, device=dev)
+        rp = A.rowptr.long()
+        cbw = max(1, -(-m // nstage))
+        row_idx = torch.repeat_interleave(torch.arange(n, **i64), rp[1:] - rp[:-1])
+        col = A.col.long()
+        cb = col // cbw
+        seglen = torch.bincount(row_idx * nstage + cb, minlength=n * nstage).view(n, nstage)
+        NB = max(1, -(-n // R))
+        order = torch.argsort(seglen, dim=0, descending=True, stable=True)            # order[i, s]: i-th longest row of stage s
+        rank = torch.empty_like(order)
+        rank.scatter_(0, order, torch.arange(n, **i64)[:, None].expand(n, nstage).contiguous())
+        rnk = rank[row_idx, cb]
+        gb = cb * NB + rnk // R                                                       # global bundle id of every nonzero
+        ukey, inv = torch.unique(gb * m + col, return_inverse=True)                   # sorted: by bundle, then column
+        nu = int(ukey.numel())
+        ub = ukey // m
+        self.ucol = (ukey % m).int().contiguous()
+        del ukey
+        uval = torch.zeros(max(nu, 1) * R, dtype=torch.float32, device=dev)
+        uval[inv * R + rnk % R] = A.val
+        self.uval = uval
+        self.union_ratio = nu / max(nnz, 1)                                           # gathers per nonzero
+        cnt_u = torch.bincount(ub, minlength=nstage * NB)                             # union size of every bundle
+        k1 = torch.cumsum(cnt_u, 0)
+        k0 = k1 - cnt_u
+        del ub, inv, rnk, gb, row_idx, col, cb
+        # bundles that exist: stage 0 lists every row (a product that overwrites C stores them all), the other stages
+        # the rows with a run there
+        rows_in = torch.cat([torch.tensor([n], **i64), (seglen[:, 1:] > 0).sum(0)])
+        nb_s = -(-rows_in // R)
+        stage_of = torch.repeat_interleave(torch.arange(nstage, **i64), nb_s)
+        b_in = torch.arange(int(nb_s.sum()), **i64) - (torch.cumsum(nb_s, 0) - nb_s)[stage_of]
+        gid = stage_of * NB + b_in
+        midx = b_in[:, None] * R + torch.arange(R, **i64)[None, :]
+        valid = midx < rows_in[stage_of][:, None]
+        members = torch.where(valid, order[midx.clamp(max=max(n - 1, 0)), stage_of[:, None].expand(-1, R)],
+                              torch.full_like(midx, -1))
+        del order, rank, seglen
+        length = cnt_u[gid]
+        pieces = torch.clamp((length + piece_len - 1) // piece_len, min=1)
+        of = torch.repeat_interleave(torch.arange(gid.numel(), **i64), pieces)
+        first = torch.cumsum(pieces, 0) - pieces
+        pidx = torch.arange(of.numel(), **i64) - first[of]
+        pk0 = k0[gid][of] + pidx * piece_len
+        pk1 = torch.minimum(pk0 + piece_len, k1[gid][of])
+        is_cut = pieces > 1
+        pcut = is_cut[of]
+        pout = torch.where(pcut, (torch.cumsum(pcut.long(), 0) - 1) * R, torch.full_like(pk0, -1))
+        pstage = stage_of[of]
+        o2 = torch.argsort(pstage * (piece_len + 1) + (piece_len - (pk1 - pk0)), stable=True)
+        desc = torch.cat([members[of], pk0[:, None], pk1[:, None], pout[:, None], torch.zeros_like(pk0)[:, None]], dim=1)
+        self.desc = desc[o2].int().contiguous()
+        self.stage_desc_off = torch.cat([torch.zeros(1, **i64), torch.cumsum(torch.bincount(pstage, minlength=nstage), 0)]).cpu().contiguous()
+        self.ndesc = int(self.desc.size(0))
+        self.npartial = int(pcut.sum().item()) * R
+        # cut list: one entry per (cut bundle, member row): {row, first partial row, pieces, R - 1}
+        cb_idx = torch.nonzero(is_cut).flatten()
+        first_out = torch.zeros(gid.numel(), **i64)
+        head = pcut & (pidx == 0)
+        first_out[of[head]] = pout[head]
+        crow = members[cb_idx]
+        cbase = first_out[cb_idx][:, None] + torch.arange(R, **i64)[None, :]
+        ccnt = pieces[cb_idx][:, None].expand(-1, R)
+        cst = stage_of[cb_idx][:, None].expand(-1, R)
+        ok = crow >= 0
+        cut = torch.stack([crow[ok], cbase[ok], ccnt[ok], torch.full_like(crow[ok], R - 1)], dim=1)
+        co = torch.argsort(cst[ok], stable=True)
+        self.cut = cut[co].int().contiguous()
+        self.stage_cut_off = torch.cat([torch.zeros(1, **i64), torch.cumsum(torch.bincount(cst[ok], minlength=nstage), 0)]).cpu().contiguous()
+        self.ncut = int(self.cut.size(0))
+        self._uncut = torch.ones(n, dtype=torch.bool, device=dev)
+        self._uncut[crow[ok]] = False
+        self.nbytes = 4 * (self.desc.numel() + self.ucol.numel() + self.uval.numel())
+        self.c = _CBundlePlan(nstage, R, self.desc.data_ptr(), self.stage_desc_off.data_ptr(), self.ucol.data_ptr(),
+                              self.uval.data_ptr(), self.cut.data_ptr(), self.stage_cut_off.data_ptr(), self.npartial)
+        self._partial = {}
+
+    partial = SegPlan.partial
+
+    def uncut_rows(self):
+        """Rows whose result is one strict chain (no bundle they belong to is cut in any stage)."""
+        return self._uncut
+
+
+def _segplan_uncut_rows(self):
+    """Rows no stage cuts into pieces: their result is the strict chain over the plan's entry order."""
+    m = torch.ones(self.n, dtype=torch.bool, device=self.seg.device)
+    if self.cut.numel():
+        m[self.cut[:, 0].long()] = False
+    return m
+
+
+SegPlan.uncut_rows = _segplan_uncut_rows

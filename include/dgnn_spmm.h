@@ -29,7 +29,7 @@ extern "C" {
 #define DGNN_E_HIP         2  /* a HIP runtime call or a kernel launch failed                 */
 #define DGNN_E_NODEVICE    3  /* no gfx950 device visible to this process                     */
 
-/* ABI version of this header: a plain counter (230 now); the Python stub refuses a library of another one. */
+/* ABI version of this header: a plain counter (240 now); the Python stub refuses a library of another one. */
 int dgnn_version(void);
 
 /* Message for the last nonzero status returned on the calling thread ("" if none). */
@@ -114,7 +114,8 @@ int dgnn_gather_rows_f32(const float* src, int64_t lds, int32_t nsrc, const int3
  *   seg            device, int32[4 * nseg]: {row, k0, k1, out} per entry, grouped by stage,
  *                  longest first inside a stage
  *   stage_seg_off  HOST, int64[nstage + 1]: entries of stage s are [off[s], off[s+1])
- *   cut            device, int32[4 * ncut]: {row, pbase, pieces, 0} per cut run, grouped by stage
+ *   cut            device, int32[4 * ncut]: {row, pbase, pieces, stride - 1} per cut run, grouped by stage: piece p of the
+ *                  run is partial row pbase + p * stride (stride 1 here: 0; row bundles: rows_per_bundle)
  *   stage_cut_off  HOST, int64[nstage + 1]
  *   npartial       rows the `partial` buffer must hold (sum of pieces over all cut runs)
  *   covers_rows    1 if the FIRST stage lists every row of the block -- rows with nothing in the first
@@ -199,6 +200,38 @@ int dgnn_spmm_plan_overwrite_f32(const dgnn_plan* plan, const int32_t* col, cons
                                  int32_t n, int32_t m, const float* B, int64_t ldb,
                                  float* C, int64_t ldc, float* partial, int64_t ldp,
                                  int32_t F, float alpha, void* stream);
+
+/*
+ * Row bundles: the fast path for blocks whose rows share many columns (hub columns; measured on the Reddit shape:
+ * 0.74x the gathers, -13..-20 % time). The stage kernel gathers one slice of a B row per nonzero, and the unit that
+ * serves gathers is what bounds it; here R rows (4 or 8; taken longest first inside a stage) are multiplied
+ * together: the union of their columns is walked once and every gathered slice feeds up to R accumulators.
+ *   desc            device, int32[(R + 4) * ndesc]: {row_0 .. row_(R-1) (-1 = none), k0, k1, out, 0} per bundle piece,
+ *                   grouped by stage, longest first; entries [k0, k1) of ucol/uval; out < 0: the rows accumulate into
+ *                   C, else the piece sums go to partial rows out + r and are merged per row (cut list, stride R)
+ *   stage_desc_off  HOST, int64[nstage + 1]
+ *   ucol            device, int32[nu]: union columns of a bundle, ascending
+ *   uval            device, float[nu * R], 16-byte aligned: entry k's value for member r at uval[k * R + r], 0 where
+ *                   that row has no nonzero in the column
+ *   cut, stage_cut_off, npartial   as in dgnn_plan ({row, pbase, pieces, R - 1})
+ * The first stage lists every row of the block. Every row sums exactly its own nonzeros in ascending column order
+ * (a zero weight leaves the accumulator as it is for finite B), so rows of uncut bundles carry the bits of
+ * dgnn_spmm_csr_f32; rows of cut bundles the fixed-order piece sums. No counterpart in the reference.
+ */
+typedef struct dgnn_bundle_plan {
+  int32_t nstage;
+  int32_t rows_per_bundle;
+  const int32_t* desc;
+  const int64_t* stage_desc_off;
+  const int32_t* ucol;
+  const float* uval;
+  const int32_t* cut;
+  const int64_t* stage_cut_off;
+  int64_t npartial;
+} dgnn_bundle_plan;
+int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                         int32_t F, float alpha, float beta, void* stream);
 
 /*
  * spmm_cusparse's operand list (row-sorted COO, spmm.cpp:16-17) on the fast kernel, for callers that hand

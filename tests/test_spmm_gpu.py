@@ -594,13 +594,12 @@ def test_full_size_configs_at_their_own_widths(shape, F):
     plan = spmm_cpp._plan_for(A, F)
     Zk = torch.zeros(n, F, device=dev)
     spmm_cpp.spmm_csr(A, B, Zk, 1.0, 0.0)                          # row kernel: the oracle's chain, element by element
-    cbw = -(-A.m // plan.nstage)
-    rows = torch.repeat_interleave(torch.arange(n, device=dev), (A.rowptr[1:] - A.rowptr[:-1]).long())
-    runs = torch.zeros(n * plan.nstage, dtype=torch.long, device=dev)
-    runs.index_add_(0, rows * plan.nstage + A.col.long() // cbw, torch.ones_like(rows))
-    del rows
-    uncut = runs.view(n, plan.nstage).amax(1) <= plan.piece_len
+    # rows the plan does not cut into pieces (run plans: every run within the piece length; bundle plans: no bundle the
+    # row belongs to is cut): there the result is the strict chain
+    uncut = plan.uncut_rows()
     assert int(uncut.sum()) > 0.9 * n
+    if shape == 'reddit' and F >= 128:
+        assert isinstance(plan, spmm_cpp.BundlePlan) and plan.union_ratio < 0.8      # rows share columns: bundles of 4
     assert torch.equal(Z[uncut], Zk[uncut])
     exact = torch.sparse.mm(torch.sparse_coo_tensor(adj.indices(), adj.values().double(), (n, n)), B.double())
     assert ((Z.double() - exact).abs() <= 1e-5 * exact).all()
@@ -715,3 +714,48 @@ def test_hot_tile_plan_matches_the_oracle_on_its_own_entry_order(n, m, nnz, hubs
     again = torch.from_numpy(C0).to(dev)
     spmm_cpp.spmm_plan(blk, Bp, again, alpha, beta, plan)
     assert torch.equal(again, Cg)
+
+
+@pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece,R,alpha,beta', [
+    (3000, 5000, 200000, 3, 256, 2, 512, 4, 1.0, 1.0), (2500, 4000, 150000, 2, 100, 3, 256, 8, 0.5, 2.0),
+    (1501, 9000, 120000, 2, 602, 4, 1024, 4, 1.0, 0.0), (4003, 1200, 90000, 0, 41, 1, 4096, 4, 1.0, 1.0),
+    (702, 700, 30000, 1, 64, 2, 64, 8, -1.0, 1.0), (9, 40, 60, 0, 128, 1, 16, 4, 1.0, 0.0)])
+def test_bundle_plan_matches_the_oracle(n, m, nnz, hubs, F, nstage, piece, R, alpha, beta):
+    """Row bundles (dgnn_spmm_bundle_f32): R rows share one gather per union column, absent entries weigh 0. Every row
+    of an uncut bundle carries the oracle's bits (its own nonzeros in ascending column order); rows of cut bundles meet
+    the fp64 bound; beta = 0 overwrites a NaN-filled C completely (row counts that do not divide by R, rows with no
+    nonzero in the first column block); same bits from run to run."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(n + F + R)
+    row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
+    fold = rng.random(col.size) < 0.5                                    # popular columns, so that rows share some
+    col = np.where(fold, col % 61, col).astype(np.int32)
+    key = np.unique(row.astype(np.int64) * m + col)
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    val = rng.random(key.size, dtype=np.float32) - 0.3
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if beta == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), alpha, beta)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    plan = spmm_cpp.BundlePlan(blk, nstage, R, piece)
+    assert plan.union_ratio < 1.0 and plan.R == R
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+    Cg = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, Cg, alpha, beta, plan)
+    got = Cg.cpu().numpy()
+    assert np.isfinite(got).all()
+    rowptr = ref_cpu.coo2csr(row, n)
+    _check(got, want, rowptr, col, val, B, np.nan_to_num(C0), alpha, beta)
+    uncut = plan.uncut_rows().cpu().numpy()
+    assert (uncut.sum() >= n // 2 or piece < 256) and np.array_equal(got[uncut], want[uncut])     # piece 64: every bundle is cut
+    again = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, again, alpha, beta, plan)
+    assert torch.equal(again, Cg)
+    if beta == 0.0:                                                       # the overwrite entry of the pipeline's first stage
+        over = torch.full((n, F), float('nan'), device=dev)
+        spmm_cpp.spmm_plan(blk, Bp, over, alpha, 1.0, plan, overwrite=True)
+        assert torch.equal(over, Cg)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy the summaries of one tools/profile_round.sh run into profiles/ and recompute profiles/traffic.json.
-   python tools/update_profiles.py gpurun_out/prof_<tag> r01"""
+   python tools/update_profiles.py gpurun_out/prof_<tag> r02 <commit>"""
 import json
 import os
 import re
@@ -27,7 +27,7 @@ def parse(p):
     out, name = {}, None
     for l in open(p):
         if l.startswith('void'):
-            name = re.search(r'spmm_stage_kernel<[^>]*>', l).group(0)
+            name = re.search(r'spmm_(?:stage|bundle|hot)_kernel<[^>]*>', l).group(0)
         else:
             m = re.search(r'n=\s*(\d+) mean=([\d.e+]+) sum=([\d.e+]+)', l)
             if m:
@@ -43,9 +43,10 @@ write = sum(v[1] for v in w.values()) * 1024
 per = {k: dict(launches=f[k][0], fetch_bytes_per_launch=int(f[k][1] * 2048 / f[k][0]),
                write_bytes_per_launch=int(w[k][1] * 1024 / w[k][0])) for k in f}
 d = dict(hbm_bytes_per_launch=int((fetch + write) / n), launches_in_pass=n, fetch_bytes_per_launch=int(fetch / n),
-         write_bytes_per_launch=int(write / n), per_kernel=per,
+         write_bytes_per_launch=int(write / n), per_kernel=per, commit=(sys.argv[3] if len(sys.argv) > 3 else 'unknown'),
+         command='python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2',
          how="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-budget 0 "
              "--steps 3 --warmup 2` (KiB per dispatch; FETCH_SIZE doubled for gfx950 per MI355X_MICROARCH.md), averaged "
-             "over all spmm_stage_kernel launches of the pass; counts L2-side fabric requests, Infinity-Cache hits included")
+             "over all SpMM stage launches of the pass (spmm_bundle_kernel and spmm_stage_kernel); counts L2-side fabric requests, Infinity-Cache hits included")
 json.dump(d, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
 print(json.dumps(d, indent=1))

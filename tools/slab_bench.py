@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--parts', type=int, default=8)
     ap.add_argument('--rank', type=int, default=0)
     ap.add_argument('--F', default='602,256,41')
+    ap.add_argument('--compact', action='store_true', help='also time the needed-rows operand: P compact blocks vs one compact slab')
     ap.add_argument('--lean', action='store_true', help='synthetic.make_partition: build only this rank\'s part')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -56,6 +57,25 @@ def main():
     A_slab = spmm_cpp.CsrBlock.from_coo(slab)
     A_blk = [spmm_cpp.CsrBlock.from_coo(b) for b in blocks]
     print(f'# {args.shape} rank {args.rank} of {P}: slab {s} x {s * P}, nnz {A_slab.nnz}', flush=True)
+    compact = None
+    if args.compact:
+        cb, offs, at = [], [0], 0
+        rows_all, cols_all, vals_all = [], [], []
+        for j, b in enumerate(blocks):
+            idx = b.indices()
+            if j == args.rank:
+                inv, k = idx[1], s
+            else:
+                cols, inv = torch.unique(idx[1], sorted=True, return_inverse=True)
+                k = max(int(cols.numel()), 1)
+            cb.append(spmm_cpp.CsrBlock.from_coo(torch.sparse_coo_tensor(torch.stack([idx[0], inv]), b.values(), (s, k), is_coalesced=True)))
+            rows_all.append(idx[0]); cols_all.append(inv + at); vals_all.append(b.values())
+            at += k
+            offs.append(at)
+        rows_all, cols_all, vals_all = torch.cat(rows_all), torch.cat(cols_all), torch.cat(vals_all)
+        order = torch.argsort(rows_all * at + cols_all)
+        cs = torch.sparse_coo_tensor(torch.stack([rows_all[order], cols_all[order]]), vals_all[order], (s, at), is_coalesced=True)
+        compact = (cb, spmm_cpp.CsrBlock.from_coo(cs), offs, at)
     for F in [int(x) for x in args.F.split(',')]:
         H = torch.rand(s * P, spmm_cpp.padded_width(F), device=dev)      # already at the padded pitch
         z1 = torch.zeros(s, F, device=dev)
@@ -72,6 +92,25 @@ def main():
         tb, tf = timed(per_block), timed(fused)
         print(f'F={F:4d}  {P} block SpMMs {tb:7.3f} ms   one slab SpMM {tf:7.3f} ms   same bits: {same}   '
               f'(gathered H: {H.numel() * 4 / 2**30:.1f} GiB)', flush=True)
+        # the needed-rows forms: every remote block against only the rows it references (columns renumbered), as P
+        # compact products or as ONE product of the compact row slab (NeededRows.compact_slab builds the same matrix)
+        if compact is not None:
+            cblocks, cslab, offs, rows_c = compact
+            Hc = torch.rand(rows_c, spmm_cpp.padded_width(F), device=dev)
+            z3 = torch.zeros(s, F, device=dev)
+            z4 = torch.zeros(s, F, device=dev)
+
+            def per_compact():
+                for j, blk in enumerate(cblocks):
+                    spmm_cpp.aggregate(blk, Hc[offs[j]:offs[j + 1], :F], z3)
+
+            def fused_compact():
+                spmm_cpp.aggregate(cslab, Hc[:, :F], z4)
+            z3.zero_(); per_compact(); z4.zero_(); fused_compact()
+            tb2, tf2 = timed(per_compact), timed(fused_compact)
+            print(f'F={F:4d}  needed rows only ({rows_c} of {s * P} rows = {rows_c / (s * P):.2f}): {P} compact block SpMMs {tb2:7.3f} ms   '
+                  f'one compact-slab SpMM {tf2:7.3f} ms   same bits: {torch.equal(z3, z4)}', flush=True)
+            del Hc, z3, z4
         del H, z1, z2
         torch.cuda.empty_cache()
 

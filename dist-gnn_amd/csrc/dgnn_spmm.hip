@@ -619,17 +619,21 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
     float* __restrict__ P, int64_t ldp, int32_t F, float alpha, uint32_t k, int fresh) {
   constexpr int G = 64 / L;
-  constexpr int SEGM = (R == 4 ? 128 : 64) * L / 16;          // strip entries per lane group
+  constexpr int SEGM = (R <= 4 ? 128 : 64) * L / 16;         // strip entries per lane group
+  constexpr int VE = (R % 4 == 0) ? 4 : 2;                   // floats per value vector (R = 6: three float2)
+  constexpr int NV = R / VE;
+  using VT = typename Vec<VE>::T;
+  static_assert(R % 2 == 0, "values are stored as float2 / float4 vectors");
   constexpr int PER = SEGM / L;                              // entries a lane loads per strip
   constexpr int DW = R + 4;
   __shared__ uint32_t off_all[4][G][SEGM];
-  __shared__ float4 val_all[4][G][SEGM * R / 4];
+  __shared__ VT val_all[4][G][SEGM * NV];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane / L;
   const int li = lane % L;
   uint32_t* const off = off_all[wave][g];
-  float4* const vals = val_all[wave][g];
+  VT* const vals = val_all[wave][g];
 
   const uint32_t nb = gridDim.x, b = blockIdx.x;
   const uint32_t q = nb >> 3, xcd = b & 7;                   // nb % 8 == 0 (launcher)
@@ -679,13 +683,17 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(
     for (int t = 0; t < PER && t * L < len; ++t) {
       const int kk = min(sb0 + li + t * L, se - 1);
       const uint32_t c1 = (uint32_t)ucol[kk];
-      float4 v[R / 4];
+      float v[R];
 #pragma unroll
-      for (int h = 0; h < R / 4; ++h) v[h] = *reinterpret_cast<const float4*>(uval + (int64_t)kk * R + 4 * h);
+      for (int h = 0; h < NV; ++h) ld_vec<VE>(uval + (int64_t)kk * R + VE * h, *reinterpret_cast<float(*)[VE]>(&v[VE * h]));
       off[li + t * L] = WIDE ? c1 : c1 * ldb_bytes;
 #pragma unroll
-      for (int h = 0; h < R / 4; ++h)
-        vals[(li + t * L) * (R / 4) + h] = make_float4(alpha * v[h].x, alpha * v[h].y, alpha * v[h].z, alpha * v[h].w);
+      for (int h = 0; h < NV; ++h) {
+        float sv[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) sv[e] = alpha * v[VE * h + e];
+        st_vec<VE>(reinterpret_cast<float*>(&vals[(li + t * L) * NV + h]), sv);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -706,14 +714,14 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-          for (int h = 0; h < R / 4; ++h) {
-            const float4 v = vals[(j + u) * (R / 4) + h];
-            const float vr[4] = {v.x, v.y, v.z, v.w};
+          for (int h = 0; h < NV; ++h) {
+            float vr[VE];
+            ld_vec<VE>(reinterpret_cast<const float*>(&vals[(j + u) * NV + h]), vr);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < VE; ++e) {
               const f32x2 vv = {vr[e], vr[e]};
-              a01[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01[4 * h + e]);
-              a23[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23[4 * h + e]);
+              a01[VE * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb[u].x, bb[u].y}, a01[VE * h + e]);
+              a23[VE * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb[u].z, bb[u].w}, a23[VE * h + e]);
             }
           }
         }
@@ -725,14 +733,14 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(
         if constexpr (WIDE) bb = *reinterpret_cast<const float4*>(Bbytes + ((int64_t)o * ldb_bytes + loff));
         else bb = *reinterpret_cast<const float4*>(Bbytes + (o + loff));
 #pragma unroll
-        for (int h = 0; h < R / 4; ++h) {
-          const float4 v = vals[j * (R / 4) + h];
-          const float vr[4] = {v.x, v.y, v.z, v.w};
+        for (int h = 0; h < NV; ++h) {
+          float vr[VE];
+          ld_vec<VE>(reinterpret_cast<const float*>(&vals[j * NV + h]), vr);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < VE; ++e) {
             const f32x2 vv = {vr[e], vr[e]};
-            a01[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb.x, bb.y}, a01[4 * h + e]);
-            a23[4 * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb.z, bb.w}, a23[4 * h + e]);
+            a01[VE * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb.x, bb.y}, a01[VE * h + e]);
+            a23[VE * h + e] = __builtin_elementwise_fma(vv, (f32x2){bb.z, bb.w}, a23[VE * h + e]);
           }
         }
       }
@@ -1428,7 +1436,7 @@ int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
                          int32_t F, float alpha, float beta, void* stream) {
   if (!plan) return fail(DGNN_E_BADARG, "spmm_bundle: null plan%s", "");
   const int R = plan->rows_per_bundle;
-  if (R != 4 && R != 8) return fail(DGNN_E_BADARG, "spmm_bundle: rows_per_bundle must be 4 or 8%s", "");
+  if (R != 2 && R != 4 && R != 6 && R != 8) return fail(DGNN_E_BADARG, "spmm_bundle: rows_per_bundle must be 2, 4, 6 or 8%s", "");
   if (n < 0 || m < 0 || F < 0 || plan->nstage < 0) return fail(DGNN_E_BADARG, "spmm_bundle: negative size%s", "");
   if (n == 0 || F == 0) return DGNN_OK;
   if (!C || ldc < F) return fail(DGNN_E_BADARG, "spmm_bundle: bad C%s", "");
@@ -1465,6 +1473,8 @@ int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
 #define DGNN_LB(RR, LL, UU) launch_bundle<RR, LL, UU>(vwc, wide, desc, ndesc, plan->ucol, plan->uval, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s)
       if (R == 4) rc = wg ? (u == 2 ? DGNN_LB(4, 32, 2) : u == 8 ? DGNN_LB(4, 32, 8) : DGNN_LB(4, 32, 4))
                           : (u == 2 ? DGNN_LB(4, 16, 2) : u == 8 ? DGNN_LB(4, 16, 8) : DGNN_LB(4, 16, 4));
+      else if (R == 6) rc = wg ? (u == 2 ? DGNN_LB(6, 32, 2) : DGNN_LB(6, 32, 4)) : (u == 2 ? DGNN_LB(6, 16, 2) : DGNN_LB(6, 16, 4));
+      else if (R == 2) rc = wg ? DGNN_LB(2, 32, 4) : DGNN_LB(2, 16, 4);
       else rc = wg ? (u == 2 ? DGNN_LB(8, 32, 2) : DGNN_LB(8, 32, 4)) : (u == 2 ? DGNN_LB(8, 16, 2) : DGNN_LB(8, 16, 4));
 #undef DGNN_LB
       if (rc != DGNN_OK) return rc;

@@ -635,8 +635,8 @@ class BundlePlan:
     bundles carry the strict chain's bits (``uncut_rows``). Integer work with torch ops on the block's device, once."""
 
     def __init__(self, A, nstage=1, R=4, piece_len=None):
-        if R not in (4, 8):
-            raise ValueError('R must be 4 or 8')
+        if R not in (2, 4, 6, 8):
+            raise ValueError('R must be 2, 4, 6 or 8')
         dev = A.device
         n, m, nnz = A.n, A.m, A.nnz
         nstage = max(1, int(nstage))

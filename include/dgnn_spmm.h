@@ -204,7 +204,7 @@ int dgnn_spmm_plan_overwrite_f32(const dgnn_plan* plan, const int32_t* col, cons
 /*
  * Row bundles: the fast path for blocks whose rows share many columns (hub columns; measured on the Reddit shape:
  * 0.74x the gathers, -13..-20 % time). The stage kernel gathers one slice of a B row per nonzero, and the unit that
- * serves gathers is what bounds it; here R rows (4 or 8; taken longest first inside a stage) are multiplied
+ * serves gathers is what bounds it; here R rows (2, 4, 6 or 8; taken longest first inside a stage) are multiplied
  * together: the union of their columns is walked once and every gathered slice feeds up to R accumulators.
  *   desc            device, int32[(R + 4) * ndesc]: {row_0 .. row_(R-1) (-1 = none), k0, k1, out, 0} per bundle piece,
  *                   grouped by stage, longest first; entries [k0, k1) of ucol/uval; out < 0: the rows accumulate into

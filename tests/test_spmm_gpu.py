@@ -719,7 +719,8 @@ def test_hot_tile_plan_matches_the_oracle_on_its_own_entry_order(n, m, nnz, hubs
 @pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece,R,alpha,beta', [
     (3000, 5000, 200000, 3, 256, 2, 512, 4, 1.0, 1.0), (2500, 4000, 150000, 2, 100, 3, 256, 8, 0.5, 2.0),
     (1501, 9000, 120000, 2, 602, 4, 1024, 4, 1.0, 0.0), (4003, 1200, 90000, 0, 41, 1, 4096, 4, 1.0, 1.0),
-    (702, 700, 30000, 1, 64, 2, 64, 8, -1.0, 1.0), (9, 40, 60, 0, 128, 1, 16, 4, 1.0, 0.0)])
+    (702, 700, 30000, 1, 64, 2, 64, 8, -1.0, 1.0), (9, 40, 60, 0, 128, 1, 16, 4, 1.0, 0.0),
+    (2001, 3000, 100000, 2, 256, 3, 512, 6, 1.0, 1.0), (1999, 3000, 80000, 1, 128, 2, 1024, 2, 1.0, 0.0)])
 def test_bundle_plan_matches_the_oracle(n, m, nnz, hubs, F, nstage, piece, R, alpha, beta):
     """Row bundles (dgnn_spmm_bundle_f32): R rows share one gather per union column, absent entries weigh 0. Every row
     of an uncut bundle carries the oracle's bits (its own nonzeros in ascending column order); rows of cut bundles meet

@@ -322,7 +322,7 @@ def main():
         traffic = tj.get('hbm_bytes_per_launch')
         traffic_source = ('stored: profiles/traffic.json, rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) '
                           f"of `{tj.get('command', 'python bench.py')}` at {tj.get('commit', 'an earlier commit')}; not measured in this run")
-    roofline = dict(bound='hbm', kernel='spmm_bundle_kernel + spmm_stage_kernel (every SpMM stage launch of the epoch)', achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+    roofline = dict(bound='hbm', kernel='spmm_dense_kernel + spmm_bundle_kernel + spmm_stage_kernel (every SpMM launch of the epoch)', achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(alg / launches),
                     avg_launch_ms=round(prof['stage_ms'] / launches, 4), launches=int(launches),

@@ -760,6 +760,150 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense tiles: register reuse across 32 rows where the block is dense enough to pay for the zeros.
+//
+// Graphs with hub rows and hub columns hold a large share of their nonzeros in a part of the matrix that is far
+// from sparse (Reddit shape: rows taken 32 at a time in order of length, the columns that at least 6 of a tile's
+// 32 rows reference hold 47 % of the nonzeros at 39 % density). There a gather per nonzero -- or per union entry of
+// a 4-row bundle -- is the wrong currency: the plan (dgnn_dense_plan) lists, per tile of 32 rows, those columns
+// and a dense [columns x 32] value array (0 where a row lacks the column), and one wave walks a piece of that list
+// for one 128-float feature chunk: per column ONE coalesced 512-byte slice of the B row (a float2 per lane) feeds
+// 32 rows x 2 packed FMAs whose A operands are wave-uniform and arrive through the scalar data path
+// (s_load_dwordx16 straight into the SGPR operand of v_pk_fma_f32): no LDS, no lane traffic, 32 VALU instructions
+// per vector load -- bound by the fp32 FMA rate, not by the address unit. No MFMA.
+//
+// Every output element is still one chain of fused multiply-adds in the list's (ascending column) order, zero
+// weights leaving it as it is; pieces of a long list go to partial rows and are merged in piece order.
+// The kernel accumulates into C (which the sparse remainder of the block has written before).
+// ---------------------------------------------------------------------------------------
+constexpr int DENSE_TR = 32;                  // rows of a tile = accumulator pairs per lane
+
+__device__ __forceinline__ f32x2 c2_load(const float* p, int fbase, int F, bool vw2) {
+  f32x2 a = {0.f, 0.f};
+  if (vw2 && fbase + 2 <= F) { const float2 t = *reinterpret_cast<const float2*>(p); a = {t.x, t.y}; }
+  else { if (fbase < F) a.x = p[0]; if (fbase + 1 < F) a.y = p[1]; }
+  return a;
+}
+
+__device__ __forceinline__ void c2_store(float* p, int fbase, int F, bool vw2, f32x2 a) {
+  if (vw2 && fbase + 2 <= F) *reinterpret_cast<float2*>(p) = make_float2(a.x, a.y);
+  else { if (fbase < F) p[0] = a.x; if (fbase + 1 < F) p[1] = a.y; }
+}
+
+// Rows are paired: the SGPR pair {a[2j], a[2j+1]} that a scalar load leaves 64-bit aligned is the first operand of
+// one v_pk_fma_f32 as it stands, the lane's B value is the broadcast one (op_sel on a VGPR costs nothing), so
+// acc[j][e] = (C[row 2j][fbase + e], C[row 2j + 1][fbase + e]) and no scalar move is needed per value (the CU's one
+// scalar unit could not keep up with 32 of them per column).
+template <bool ALPHA1>
+__device__ __forceinline__ void dense_fma(f32x2 (&acc)[DENSE_TR / 2][2], const float* __restrict__ a, f32x2 b, float alpha, int j0, int j1) {
+#pragma unroll
+  for (int j = 0; j < DENSE_TR / 2; ++j) {
+    if (j < j0 || j >= j1) continue;
+    f32x2 a2 = {a[2 * j], a[2 * j + 1]};
+    if (!ALPHA1) a2 = a2 * alpha;
+    acc[j][0] = __builtin_elementwise_fma(a2, (f32x2){b.x, b.x}, acc[j][0]);
+    acc[j][1] = __builtin_elementwise_fma(a2, (f32x2){b.y, b.y}, acc[j][1]);
+  }
+}
+
+template <bool ALPHA1, int DBG>
+__global__ __launch_bounds__(256) void spmm_dense_kernel(
+    const int4* __restrict__ desc, int32_t nitems, int32_t nchunk,
+    const int32_t* __restrict__ rows, const int32_t* __restrict__ kcol, const float* __restrict__ kval,
+    const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+    float* __restrict__ P, int64_t ldp, int32_t F, float alpha, int vw2) {
+  constexpr int NP = DENSE_TR / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = blockIdx.x * 4 + wave;                    // wave-uniform: everything below that does not depend
+  if (item >= nitems) return;                                // on `lane` lives in SGPRs
+  const int piece = item / nchunk, chunk = item - piece * nchunk;
+  const int4 d = desc[piece];                                // {k0, k1, tile, out}; k1 - k0 is a multiple of 8 (lists are padded)
+  const int fbase = chunk * 128 + lane * 2;
+  const bool active = fbase < (int)ldb;                      // lanes past the padded width compute on column 0, store nothing
+  const uint64_t ldb_bytes = (uint64_t)ldb * 4u;
+  const uint32_t loff = active ? (uint32_t)fbase * 4u : 0u;
+  const char* const Bb = reinterpret_cast<const char*>(B);
+  const int32_t* const rw = rows + (int64_t)d.z * DENSE_TR;
+  const bool direct = d.w < 0;
+
+  f32x2 acc[NP][2];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    f32x2 c0 = {0.f, 0.f}, c1 = {0.f, 0.f};
+    if (direct && active) {
+      const int r0 = rw[2 * j], r1 = rw[2 * j + 1];
+      if (r0 >= 0) c0 = c2_load(C + (int64_t)r0 * ldc + fbase, fbase, F, vw2 != 0);
+      if (r1 >= 0) c1 = c2_load(C + (int64_t)r1 * ldc + fbase, fbase, F, vw2 != 0);
+    }
+    acc[j][0] = (f32x2){c0.x, c1.x};
+    acc[j][1] = (f32x2){c0.y, c1.y};
+  }
+
+  const int k0 = d.x, k1 = d.y;
+  if (k0 < k1) {
+    // Two columns per trip, their value rows in two SGPR sets that are loaded in turn: the scalar load of one set is
+    // issued right after the first FMA of the other (scalar loads return out of order, so a wait covers everything
+    // outstanding: only one set may be in flight while the other is multiplied).
+    const uint32_t ldb_lo = (uint32_t)ldb_bytes;             // ldb * 4 < 2^32 (checked by the launcher)
+    auto slice = [&](int k) -> f32x2 {                         // scalar row base (SALU) + 32-bit lane offset: saddr form
+      const uint32_t c = (DBG & 2) ? (uint32_t)(k & 63) : (uint32_t)kcol[k];
+      const uint64_t off = ((uint64_t)__umulhi(c, ldb_lo) << 32) | (uint64_t)(c * ldb_lo);
+      return *reinterpret_cast<const f32x2*>(Bb + off + loff);
+    };
+    // The value rows are a cold stream (HBM) and a scalar load cannot be issued far ahead (there are SGPRs for one
+    // trip's 64 values only), so every trip would wait out a memory latency with nothing but the other waves' FMAs
+    // to cover it (measured: 57 % of the FMA rate at 4 waves per SIMD). The wave therefore touches the 256 bytes of
+    // trip t + DENSE_PF with one coalesced vector load (a dword per lane) that nobody waits for until two trips later:
+    // when the scalar loads come, the lines are in L2.
+    // Vector loads return in order, so a wait for a B slice also waits for every older load: the slices are fetched a
+    // whole trip (4 columns) ahead and the touch goes out in the middle of a trip, which gives it a trip's time to land.
+    constexpr int DENSE_PF = 16;                               // the touch runs this many columns ahead
+    auto touch = [&](int k) -> f32x2 {                         // 512 B = the value rows of 4 columns, 8 B per lane
+      return *reinterpret_cast<const f32x2*>(kval + (int64_t)min(k, k1 - 4) * DENSE_TR + lane * 2);
+    };
+    f32x2 pf = touch(k0 + DENSE_PF - 4);
+    f32x2 b0 = slice(k0), b1 = slice(k0 + 1), b2 = slice(k0 + 2), b3 = slice(k0 + 3);
+    f32x2 n0, n1, n2, n3;
+#define DENSE_TRIP(K, B0, B1, B2, B3, N0, N1, N2, N3)                                         \
+    {                                                                                         \
+      const float* const a0 = kval + (int64_t)((DBG & 1) ? ((K) & 63) : (K)) * DENSE_TR;      \
+      const int kn = min((K) + 4, k1 - 4);                                                    \
+      dense_fma<ALPHA1>(acc, a0, B0, alpha, 0, NP);                                           \
+      N0 = slice(kn);                                                                         \
+      dense_fma<ALPHA1>(acc, a0 + DENSE_TR, B1, alpha, 0, NP);                                \
+      N1 = slice(kn + 1);                                                                     \
+      asm volatile("" ::"v"(pf));          /* last trip's touch has landed (no instruction) */ \
+      pf = touch((K) + DENSE_PF);                                                             \
+      dense_fma<ALPHA1>(acc, a0 + 2 * DENSE_TR, B2, alpha, 0, NP);                            \
+      N2 = slice(kn + 2);                                                                     \
+      dense_fma<ALPHA1>(acc, a0 + 3 * DENSE_TR, B3, alpha, 0, NP);                            \
+      N3 = slice(kn + 3);                                                                     \
+    }
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 8) {                         // k1 - k0 is a multiple of 8 (lists are padded)
+      DENSE_TRIP(k, b0, b1, b2, b3, n0, n1, n2, n3)
+      DENSE_TRIP(k + 4, n0, n1, n2, n3, b0, b1, b2, b3)
+    }
+#undef DENSE_TRIP
+    asm volatile("" ::"v"(pf));
+  }
+
+  if (!active) return;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = rw[2 * j + h];
+      if (row < 0) continue;
+      const f32x2 v = h == 0 ? (f32x2){acc[j][0].x, acc[j][1].x} : (f32x2){acc[j][0].y, acc[j][1].y};
+      if (direct) c2_store(C + (int64_t)row * ldc + fbase, fbase, F, vw2 != 0, v);
+      else if (fbase < ldp) *reinterpret_cast<float2*>(P + (int64_t)(d.w + 2 * j + h) * ldp + fbase) = make_float2(v.x, v.y);
+    }
+  }
+}
+
 // C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order). One wave per cut run; a lane owns
 // float4 columns of the (16-B aligned, padded) partial rows and keeps 4 piece loads in flight.
 template <int VWC>
@@ -1206,7 +1350,7 @@ size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" {
 
-int dgnn_version(void) { return 240; }   // 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
+int dgnn_version(void) { return 250; }   // 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 
@@ -1491,6 +1635,55 @@ int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
       DGNN_HIP(hipGetLastError());
     }
     if (d1 > d0 || p1 > p0) fresh = false;
+  }
+  return DGNN_OK;
+}
+
+int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                        int32_t F, float alpha, void* stream) {
+  if (!plan) return fail(DGNN_E_BADARG, "spmm_dense: null plan%s", "");
+  if (plan->rows_per_tile != DENSE_TR) return fail(DGNN_E_BADARG, "spmm_dense: rows_per_tile must be 32%s", "");
+  if (n < 0 || m < 0 || F < 0 || plan->npiece < 0 || plan->ncut < 0 || plan->ntile < 0 || plan->nk < 0)
+    return fail(DGNN_E_BADARG, "spmm_dense: negative size%s", "");
+  if (n == 0 || F == 0 || plan->npiece == 0) return DGNN_OK;
+  if (!C || ldc < F) return fail(DGNN_E_BADARG, "spmm_dense: bad C%s", "");
+  if (!plan->desc || !plan->rows || !plan->kcol || !plan->kval || !B) return fail(DGNN_E_BADARG, "spmm_dense: null pointer%s", "");
+  if (ldb < F || ldb % 4 != 0 || !aligned(B, 16) || !aligned(plan->kval, 4))
+    return fail(DGNN_E_BADARG, "spmm_dense: B needs ldb >= F, ldb %% 4 == 0 and a 16-byte aligned base (dgnn_pad_rows_f32)%s", "");
+  if (plan->ncut > 0 && (!partial || !plan->cut || ldp < ldb || ldp % 4 != 0 || !aligned(partial, 16)))
+    return fail(DGNN_E_BADARG, "spmm_dense: cut tiles need a 16-byte aligned partial buffer with ldp >= ldb, ldp %% 4 == 0%s", "");
+  if (overlap(B, m, ldb, C, n, ldc, F)) return fail(DGNN_E_BADARG, "spmm_dense: B and C overlap%s", "");
+  if (ldb >= (1ll << 30)) return fail(DGNN_E_BADARG, "spmm_dense: ldb out of range%s", "");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nchunk = (ldb + 127) / 128;
+  const int64_t nitems = (int64_t)plan->npiece * nchunk;
+  if (nitems > 0x7fffffffLL) return fail(DGNN_E_BADARG, "spmm_dense: grid out of range%s (%lld)", "", nitems);
+  const int vw2 = (ldc % 2 == 0 && aligned(C, 8)) ? 1 : 0;
+  const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : (vw2 ? 2 : 1);
+  {
+    ProfScope prof(s, 0);
+    const dim3 grid((unsigned)((nitems + 3) / 4));
+    const int4* desc = reinterpret_cast<const int4*>(plan->desc);
+#define DGNN_DENSE(A1, W)                                                                                             \
+    hipLaunchKernelGGL((spmm_dense_kernel<A1, W>), grid, dim3(256), 0, s, desc, (int32_t)nitems, (int32_t)nchunk, plan->rows, \
+                       plan->kcol, plan->kval, B, ldb, C, ldc, partial, ldp, F, alpha, vw2)
+    if (alpha != 1.f) DGNN_DENSE(false, 0);
+    else if (g_variant == 301) DGNN_DENSE(true, 1);
+    else if (g_variant == 302) DGNN_DENSE(true, 2);
+    else if (g_variant == 303) DGNN_DENSE(true, 3);
+    else DGNN_DENSE(true, 0);
+#undef DGNN_DENSE
+    DGNN_HIP(hipGetLastError());
+  }
+  if (plan->ncut > 0) {
+    ProfScope prof(s, 1);
+    const dim3 grid((unsigned)((plan->ncut + 3) / 4));
+    const int4* cutp = reinterpret_cast<const int4*>(plan->cut);
+    if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, plan->ncut, partial, ldp, C, ldc, F, 0);
+    else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, plan->ncut, partial, ldp, C, ldc, F, 0);
+    else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, plan->ncut, partial, ldp, C, ldc, F, 0);
+    DGNN_HIP(hipGetLastError());
   }
   return DGNN_OK;
 }

@@ -46,6 +46,11 @@ class _CBundlePlan(ctypes.Structure):    # struct dgnn_bundle_plan (include/dgnn
                 ('cut', _p), ('stage_cut_off', _p), ('npartial', _i64)]
 
 
+class _CDensePlan(ctypes.Structure):     # struct dgnn_dense_plan (include/dgnn_spmm.h)
+    _fields_ = [('rows_per_tile', _i32), ('ntile', _i32), ('npiece', _i32), ('ncut', _i32), ('desc', _p), ('rows', _p),
+                ('kcol', _p), ('kval', _p), ('cut', _p), ('nk', _i64), ('npartial', _i64)]
+
+
 class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn_spmm.h)
     _fields_ = [('nstage', _i32), ('piece', _i32), ('hdr_ints', _i64), ('nseg_max', _i64), ('ncut_max', _i64),
                 ('npartial_max', _i64), ('ws_ints', _i64)]
@@ -73,13 +78,14 @@ _SIGNATURES = {                          # argument types, in the order of inclu
     'dgnn_plan_build': [_p, _p, _i32, _i32, ctypes.POINTER(_CLayout), _p, _p],
     'dgnn_spmm_plan_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
     'dgnn_spmm_bundle_f32': [ctypes.POINTER(_CBundlePlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
+    'dgnn_spmm_dense_f32': [ctypes.POINTER(_CDensePlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
     'dgnn_spmm_plan_overwrite_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
 }
 for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_ABI = 240                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+_ABI = 250                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
 if _lib.dgnn_version() != _ABI:
     raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
                        'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')
@@ -502,6 +508,22 @@ def _plan_for(A, F):
     device-built plan, measured on Reddit and products shapes). DGNN_PLAN_BUILDER=device builds it with
     dgnn_plan_build instead: no sorts over the nonzeros, no host synchronisation, a third of the set-up
     time -- what very large blocks want."""
+    # Dense tiles (DensePlan): where a block holds a large share of its nonzeros in tiles of 32 rows x their common
+    # columns (hub rows x hub columns), that part runs as register-tiled fp32 FMAs and the plans below are built for the
+    # sparse remainder. Feature blocks of at least 128 floats only (one wave = one 128-float chunk).
+    if padded_width(F) >= 128 and not int(os.environ.get('DGNN_HOT_ROWS', 0) or 0) \
+            and os.environ.get('DGNN_PLAN_BUILDER', 'torch') != 'device':
+        D = _dense_for(A)
+        if D is not None:
+            hp = A.__dict__.setdefault('_hybrid', {})
+            rest_plan = _plan_for_sparse(D.rest, F)
+            if id(rest_plan) not in hp:
+                hp[id(rest_plan)] = HybridPlan(D, rest_plan)
+            return hp[id(rest_plan)]
+    return _plan_for_sparse(A, F)
+
+
+def _plan_for_sparse(A, F):
     ns = default_stage_count(A.n, A.m, A.nnz, F)
     # DGNN_HOT_ROWS=256|512 (opt-in, measured slower on every shape tried, DESIGN.md 3.1): hot-tile plans -- the
     # B rows of each stage's most referenced columns staged in LDS. Only for blocks with enough work per stage.
@@ -576,6 +598,10 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
         raise RuntimeError('spmm_plan: operands are on different devices')
     if plan is None:
         plan = _plan_for(A, F)
+    if isinstance(plan, HybridPlan):                     # sparse remainder first (it owns beta / overwrite), then the tiles
+        spmm_plan(plan.dense.rest, B, C, alpha, beta, plan=plan.rest_plan, overwrite=overwrite)
+        spmm_dense(plan.dense, B, C, alpha)
+        return
     dev = C.device
     P = plan.partial(ldb, dev)
     if isinstance(plan, BundlePlan):
@@ -736,3 +762,201 @@ def _segplan_uncut_rows(self):
 
 
 SegPlan.uncut_rows = _segplan_uncut_rows
+
+
+# --------------------------------------------------------------------------- dense tiles (the part of a block that is not sparse)
+DENSE_TR = 32                # rows of a dense tile (DENSE_TR in the library)
+
+
+class DensePlan:
+    """``struct dgnn_dense_plan`` for one CsrBlock, plus the sparse remainder of the block.
+
+    Rows are ranked by length and taken ``DENSE_TR`` = 32 at a time (a tile). A column that at least ``min_count`` of a
+    tile's rows reference is *listed* for that tile; tiles with fewer than ``min_cols`` listed columns list nothing
+    (their rows stay untouched: the strict chain). The listed entries leave the CSR block -- ``self.rest`` is the
+    CsrBlock of what remains -- and are stored densely: ``kval[32 * k + r]`` = value of member r in listed column k
+    (0 where the row lacks it). ``spmm_dense_kernel`` walks a tile's list once per 128-float feature chunk: one
+    coalesced slice of a B row per listed column feeds 32 rows. A list much longer than ``piece_len`` is cut into pieces
+    at column boundaries (partial rows, merged in piece order). Integer work with torch ops on the block's device, once
+    per block. Defaults from sweeps on the Reddit shape (profiles/r02_dense_*.txt): min_count 5, min_cols 128,
+    piece_len 1024.
+
+    ``share``: fraction of the block's nonzeros that moved into tiles; ``density``: nonzeros per tile cell.
+    """
+
+    def __init__(self, A, min_count=None, min_cols=None, piece_len=None, keep_mask=False):
+        TR = DENSE_TR
+        dev = A.device
+        n, m, nnz = A.n, A.m, A.nnz
+        if min_count is None:
+            min_count = int(os.environ.get('DGNN_DENSE_MIN_COUNT', 5))
+        if min_cols is None:
+            min_cols = int(os.environ.get('DGNN_DENSE_MIN_COLS', 128))
+        if piece_len is None:
+            piece_len = int(os.environ.get('DGNN_DENSE_PIECE', 1024))
+        if piece_len < 8 or piece_len % 8:
+            raise ValueError('piece_len must be a multiple of 8')
+        self.min_count, self.min_cols, self.piece_len = int(min_count), int(min_cols), int(piece_len)
+        i64 = dict(dtype=torch.long, device=dev)
+        rp = A.rowptr.long()
+        deg = rp[1:] - rp[:-1]
+        ntile = max(1, -(-n // TR))
+        order = torch.argsort(deg, descending=True, stable=True)
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(n, **i64)
+        row_idx = torch.repeat_interleave(torch.arange(n, **i64), deg)
+        rnk = rank[row_idx]
+        col = A.col.long()
+        ukey, inv, cnt = torch.unique((rnk // TR) * m + col, return_inverse=True, return_counts=True)   # by tile, then column
+        utile = ukey // m
+        sel = cnt >= self.min_count
+        per_tile = torch.bincount(utile[sel], minlength=ntile)
+        sel &= (per_tile >= self.min_cols)[utile]                       # tiles with a short list keep their rows whole
+        # A tile's list is cut into pieces at COLUMN boundaries: a tile with many listed columns splits the column range
+        # into nb (a power of two, ~piece_len listed columns per part) equal blocks, and the pieces of all tiles are
+        # worked off in column order -- the waves in flight at any moment read B rows of one narrow column range, which
+        # the L2s hold (measured: the tiles' B traffic is what bounds the kernel otherwise). A piece's slots are padded
+        # to a multiple of 8 columns (what the kernel takes per loop trip): pad slots repeat its last column with zero
+        # weights.
+        lt = utile[sel]
+        lc = ukey[sel] % m
+        listed = int(lt.numel())
+        cnt_t = torch.bincount(lt, minlength=ntile)
+        want = torch.clamp((cnt_t + self.piece_len - 1) // self.piece_len, min=1)
+        nb_t = torch.ones_like(want)
+        while bool((nb_t < want).any()):
+            nb_t = torch.where(nb_t < want, nb_t * 2, nb_t)
+        bw_t = (m + nb_t - 1) // nb_t
+        pbase_t = torch.cumsum(nb_t, 0) - nb_t
+        npot = int(nb_t.sum().item())
+        pid = pbase_t[lt] + lc // bw_t[lt]                              # ascending: the pairs are sorted by (tile, column)
+        cnt_piece = torch.bincount(pid, minlength=npot)
+        cnt_pp = (cnt_piece + 7) // 8 * 8
+        k1 = torch.cumsum(cnt_pp, 0)
+        k0 = k1 - cnt_pp
+        nk = int(k1[-1].item()) if npot else 0
+        first_of_piece = torch.cumsum(cnt_piece, 0) - cnt_piece
+        slot_l = k0[pid] + (torch.arange(listed, **i64) - first_of_piece[pid])
+        kcol = torch.zeros(max(nk, 1), **i64)
+        kcol[slot_l] = lc
+        for j in range(1, 8):
+            short = torch.nonzero(((cnt_pp - cnt_piece) >= j) & (cnt_piece > 0)).flatten()
+            kcol[k1[short] - j] = kcol[k0[short] + cnt_piece[short] - 1]
+        self.kcol = kcol.int().contiguous()
+        slot = torch.full((ukey.numel(),), -1, **i64)
+        slot[sel] = slot_l
+        in_dense = sel[inv]
+        kval = torch.zeros(max(nk, 1) * TR, dtype=torch.float32, device=dev)
+        kval[slot[inv[in_dense]] * TR + rnk[in_dense] % TR] = A.val[in_dense]
+        self.kval = kval
+        self.nk, self.listed = nk, listed
+        moved = int(in_dense.sum().item())
+        self.share = moved / max(nnz, 1)
+        self.density = moved / max(listed * TR, 1)
+        self.in_dense = in_dense if keep_mask else None                 # tests: which entries of A moved
+        # the sparse remainder, as a CsrBlock of its own
+        keep = ~in_dense
+        rest_rp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        rest_rp[1:] = torch.cumsum(torch.bincount(row_idx[keep], minlength=n), 0).int()
+        self.rest = CsrBlock(n, m, rest_rp, A.col[keep].contiguous(), A.val[keep].contiguous())
+        del ukey, inv, cnt, utile, sel, slot, slot_l, pid, lt, lc, in_dense, keep, row_idx, rnk, col
+        # pieces in working order: by first column of their column block, longest first inside one
+        rows = torch.full((ntile * TR,), -1, **i64)
+        rows[:n] = order
+        self.rows = rows.int().contiguous()
+        pidx = torch.nonzero(cnt_piece > 0).flatten()                  # in (tile, block) order
+        ptile = torch.repeat_interleave(torch.arange(ntile, **i64), nb_t)[pidx]
+        pstart = (pidx - pbase_t[ptile]) * bw_t[ptile]
+        plen = cnt_pp[pidx]
+        per_tile_pieces = torch.bincount(ptile, minlength=ntile)
+        tid = torch.nonzero(per_tile_pieces > 0).flatten()
+        self.tiles = tid                                               # tiles that list something
+        pcut = (per_tile_pieces > 1)[ptile]
+        pout = torch.where(pcut, (torch.cumsum(pcut.long(), 0) - 1) * TR, torch.full_like(plen, -1))
+        maxlen = int(plen.max().item()) if plen.numel() else 0
+        self.max_piece = maxlen
+        o2 = torch.argsort(pstart * (maxlen + 1) + (maxlen - plen), stable=True)
+        self.desc = torch.stack([k0[pidx], k1[pidx], ptile, pout], dim=1)[o2].int().contiguous()
+        self.npiece = int(self.desc.size(0))
+        self.npartial = int(pcut.sum().item()) * TR
+        # cut list: one entry per (cut tile, member row): {row, first partial row, pieces, TR - 1}
+        ct = torch.nonzero(per_tile_pieces > 1).flatten()              # cut tiles
+        first_piece_of_tile = torch.cumsum(per_tile_pieces, 0) - per_tile_pieces
+        first_out = pout[first_piece_of_tile[ct]] if ct.numel() else torch.zeros(0, **i64)
+        crow = self.rows.long().view(ntile, TR)[ct]
+        cbase = first_out[:, None] + torch.arange(TR, **i64)[None, :]
+        ccnt = per_tile_pieces[ct][:, None].expand(-1, TR)
+        ok = crow >= 0
+        self.cut = torch.stack([crow[ok], cbase[ok], ccnt[ok], torch.full_like(crow[ok], TR - 1)], dim=1).int().contiguous()
+        self.ncut = int(self.cut.size(0))
+        self.ntile = ntile
+        touched = torch.zeros(ntile * TR, dtype=torch.bool, device=dev)
+        touched.view(ntile, TR)[tid] = True
+        self._touched_rows = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._touched_rows[order] = touched[:n]
+        self._cut_rows = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._cut_rows[crow[ok]] = True
+        self.nbytes = 4 * (self.desc.numel() + self.rows.numel() + self.kcol.numel() + self.kval.numel() + self.cut.numel())
+        self.c = _CDensePlan(TR, ntile, self.npiece, self.ncut, self.desc.data_ptr(), self.rows.data_ptr(),
+                             self.kcol.data_ptr(), self.kval.data_ptr(), self.cut.data_ptr(), nk, self.npartial)
+        self._partial = {}
+
+    partial = SegPlan.partial
+
+    def touched_rows(self):
+        """Rows that belong to a tile with a list: their chain is [remainder entries, then the listed entries]."""
+        return self._touched_rows
+
+    def cut_rows(self):
+        """Rows of tiles whose list is cut into pieces (fixed-order piece sums instead of one chain)."""
+        return self._cut_rows
+
+
+class HybridPlan:
+    """A block as dense tiles + sparse remainder: ``rest_plan`` (a SegPlan / BundlePlan of ``dense.rest``) runs first,
+    with the call's beta / overwrite; ``dgnn_spmm_dense_f32`` then adds the tiles."""
+
+    def __init__(self, dense, rest_plan):
+        self.dense, self.rest_plan = dense, rest_plan
+
+    def uncut_rows(self):
+        """Rows whose result is one strict chain over the plan's own entry order (remainder ascending, then listed
+        columns ascending)."""
+        return self.rest_plan.uncut_rows() & ~self.dense.cut_rows()
+
+    def strict_rows(self):
+        """Rows whose result is the strict chain over A's own (ascending column) order: uncut and in no tile."""
+        return self.rest_plan.uncut_rows() & ~self.dense.touched_rows()
+
+
+def spmm_dense(D, B, C, alpha=1.0):
+    """C += alpha * (dense tiles of D) @ B[:, :F]; B a padded feature block (pad_rows)."""
+    bptr, ldb = _dense(B, 'B')
+    cptr, ldc = _dense(C, 'C')
+    F = C.size(1)
+    dev = C.device
+    P = D.partial(ldb, dev)
+    args = (ctypes.byref(D.c), D.rest.n, D.rest.m, bptr, ldb, cptr, ldc, P.data_ptr(), ldb, F, float(alpha))
+    if torch.cuda.current_device() == dev.index:
+        rc = _lib.dgnn_spmm_dense_f32(*args, _stream(C))
+    else:
+        with torch.cuda.device(dev):
+            rc = _lib.dgnn_spmm_dense_f32(*args, _stream(C))
+    _check(rc, 'spmm_dense')
+
+
+def _dense_for(A):
+    """The DensePlan of a block if dense tiles pay for it, else None (decided once per block). DGNN_DENSE=0 never,
+    DGNN_DENSE=1 whenever any tile lists something, default: when the tiles take at least a fifth of the nonzeros."""
+    want = os.environ.get('DGNN_DENSE', 'auto')
+    # blocks under ~8 M nonzeros (the blocks of a 4- or 8-rank partition) are too small for it: a few hundred pieces do
+    # not fill the chip (measured on an 8-way Reddit-shaped partition: 8 block products 1.8 -> 2.8 ms, while the rank's
+    # 14 M-nonzero row slab gains 10 %)
+    if want == '0' or A.nnz < (1 << 23) or float(A.nnz) / max(A.n, 1) < 32:
+        return None
+    if '_dense_plan' not in A.__dict__:
+        D = DensePlan(A)
+        if D.nk == 0 or (want != '1' and D.share < 0.2):
+            D = None
+        A.__dict__['_dense_plan'] = D
+    return A.__dict__['_dense_plan']

@@ -29,7 +29,7 @@ extern "C" {
 #define DGNN_E_HIP         2  /* a HIP runtime call or a kernel launch failed                 */
 #define DGNN_E_NODEVICE    3  /* no gfx950 device visible to this process                     */
 
-/* ABI version of this header: a plain counter (240 now); the Python stub refuses a library of another one. */
+/* ABI version of this header: a plain counter (250 now); the Python stub refuses a library of another one. */
 int dgnn_version(void);
 
 /* Message for the last nonzero status returned on the calling thread ("" if none). */
@@ -232,6 +232,45 @@ typedef struct dgnn_bundle_plan {
 int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
                          const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
                          int32_t F, float alpha, float beta, void* stream);
+
+/*
+ * Dense tiles: the part of a block that is not sparse. On graphs with hub rows and hub columns (Reddit shape: rows
+ * taken 32 at a time in order of length, the columns at least 6 of the 32 reference: 47 % of the nonzeros at 39 %
+ * density) a gather per nonzero is the wrong currency; there one coalesced slice of a B row feeds 32 rows' fused
+ * multiply-adds whose A operands are wave-uniform (scalar loads). The host-side builder (spmm_cpp.DensePlan) moves
+ * those entries out of the CSR block -- the sparse remainder goes through dgnn_spmm_plan_f32 / dgnn_spmm_bundle_f32
+ * first -- and this call ADDS the dense part:  C += alpha * A_dense * B.
+ *   rows_per_tile  32
+ *   rows           device, int32[32 * ntile]: member rows of every tile (-1 = none)
+ *   kcol           device, int32[nk]: the listed columns (slots), piece after piece, ascending inside a piece
+ *   kval           device, float[32 * nk]: value of member r in slot k at kval[32 * k + r], 0 where the row has no such
+ *                  nonzero
+ *   desc           device, int32[4 * npiece]: {k0, k1, tile, out} per piece (slots [k0, k1) of one tile's list; k1 - k0 a
+ *                  positive multiple of 8 -- pad slots repeat a column with zero weights; kcol/kval hold at least 8
+ *                  slots), in working order; out < 0: the members accumulate into C, else the piece sums go to partial
+ *                  rows out + r and are merged per row (cut list {row, first partial row, pieces, 31}, as in dgnn_plan)
+ *   npartial       rows the partial buffer must hold
+ * An output element is one chain of fused multiply-adds over the tile's list in ascending column order, continuing
+ * from what C holds (a zero weight leaves it as it is for finite B): rows of uncut tiles carry the bits of the strict
+ * chain over [remainder entries, then listed entries]; rows of cut tiles the fixed-order piece sums. No MFMA, no
+ * atomics. No counterpart in the reference.
+ */
+typedef struct dgnn_dense_plan {
+  int32_t rows_per_tile;
+  int32_t ntile;
+  int32_t npiece;
+  int32_t ncut;
+  const int32_t* desc;
+  const int32_t* rows;
+  const int32_t* kcol;
+  const float* kval;
+  const int32_t* cut;
+  int64_t nk;
+  int64_t npartial;
+} dgnn_dense_plan;
+int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                        int32_t F, float alpha, void* stream);
 
 /*
  * spmm_cusparse's operand list (row-sorted COO, spmm.cpp:16-17) on the fast kernel, for callers that hand

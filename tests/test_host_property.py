@@ -66,3 +66,59 @@ def test_normalise_split_partition_match_the_oracle(c):
         assert np.array_equal(pg.features.numpy(), view['features'])
         assert np.array_equal(pg.local_labels.numpy(), view['local_labels'])
         assert np.array_equal(pg.local_train_mask.numpy(), view['local_train_mask'])
+
+
+def test_dense_plan_splits_a_block_into_tiles_and_remainder_exactly():
+    """spmm_cpp.DensePlan is integer work with torch ops and runs without a GPU: tiles + remainder hold every entry of
+    the block exactly once (same values), piece lengths are multiples of 8 (pad slots weigh 0), every slot belongs to
+    one piece, the pieces of a cut tile own consecutive partial rows, and tiles under min_cols stay untouched."""
+    import numpy as np
+    import torch
+    import spmm_cpp
+    from coo_graph import synthetic, graph_utils
+    n = 2500
+    d = synthetic.make_dataset('reddit', seed=3, device='cpu', num_nodes=n, num_edges=300000, with_features=False)
+    adj = graph_utils.sym_normalization(d['edge_index'], n).coalesce()
+    idx, val = adj.indices(), adj.values()
+    rp = torch.zeros(n + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(torch.bincount(idx[0], minlength=n), 0).int()
+    A = spmm_cpp.CsrBlock(n, n, rp, idx[1].int(), val)
+    for min_count, min_cols, piece in ((6, 16, 64), (3, 200, 1024)):
+        D = spmm_cpp.DensePlan(A, min_count, min_cols, piece, keep_mask=True)
+        assert 0.2 < D.share < 1.0 and D.density >= min_count / 32 and D.nk % 8 == 0
+        rows = D.rows.long().view(-1, 32)
+        desc = D.desc.long().numpy()
+        dense = np.zeros((n, n))
+        seen = np.zeros(D.nk, dtype=np.int64)
+        kcol, kval = D.kcol.numpy(), D.kval.view(-1, 32).numpy()
+        per_tile = {}
+        for k0, k1, t, out in desc:
+            assert k1 > k0 and (k1 - k0) % 8 == 0
+            seen[k0:k1] += 1
+            r = rows[t].numpy()
+            ok = r >= 0
+            assert (kval[k0:k1][:, ~ok] == 0).all()
+            cols = kcol[k0:k1]
+            assert (np.diff(cols) >= 0).all()                              # ascending (pad slots repeat the last column)
+            np.add.at(dense, (np.repeat(r[ok][None, :], k1 - k0, 0), np.repeat(cols[:, None], ok.sum(), 1)), kval[k0:k1][:, ok])
+            per_tile.setdefault(int(t), []).append((int(k0), int(out)))
+        assert (seen == 1).all()
+        R = D.rest
+        ri = np.repeat(np.arange(n), np.diff(R.rowptr.numpy()))
+        rest = np.zeros((n, n))
+        rest[ri, R.col.numpy()] = R.val.numpy()
+        assert np.array_equal(dense + rest, adj.to_dense().numpy().astype(np.float64))
+        assert R.nnz + int(D.in_dense.sum()) == A.nnz
+        cut = {int(c[0]): (int(c[1]), int(c[2]), int(c[3])) for c in D.cut.numpy()}
+        for t, pieces in per_tile.items():
+            members = rows[t][rows[t] >= 0].tolist()
+            if len(pieces) == 1:
+                assert pieces[0][1] == -1 and not any(r in cut for r in members)
+            else:
+                outs = sorted(o for _, o in sorted(pieces))
+                assert outs == list(range(outs[0], outs[0] + 32 * len(pieces), 32))
+                for j, r in enumerate(rows[t].tolist()):
+                    if r >= 0:
+                        assert cut[r] == (outs[0] + j, len(pieces), 31)
+        assert int(D.touched_rows().sum()) == sum(int((rows[t] >= 0).sum()) for t in per_tile)
+        assert D.npartial == 32 * sum(len(p) for p in per_tile.values() if len(p) > 1)

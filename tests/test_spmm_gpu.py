@@ -597,9 +597,14 @@ def test_full_size_configs_at_their_own_widths(shape, F):
     # rows the plan does not cut into pieces (run plans: every run within the piece length; bundle plans: no bundle the
     # row belongs to is cut): there the result is the strict chain
     uncut = plan.uncut_rows()
-    assert int(uncut.sum()) > 0.9 * n
     if shape == 'reddit' and F >= 128:
-        assert isinstance(plan, spmm_cpp.BundlePlan) and plan.union_ratio < 0.8      # rows share columns: bundles of 4
+        # hub rows x hub columns run as dense tiles (half of the nonzeros), the remainder through the sparse plan; rows
+        # that belong to no tile (the lighter three quarters) keep the strict chain over ascending columns
+        assert isinstance(plan, spmm_cpp.HybridPlan) and plan.dense.share > 0.4 and plan.dense.density > 0.25
+        uncut = plan.strict_rows()
+        assert int(uncut.sum()) > 0.7 * n
+    else:
+        assert int(uncut.sum()) > 0.9 * n
     assert torch.equal(Z[uncut], Zk[uncut])
     exact = torch.sparse.mm(torch.sparse_coo_tensor(adj.indices(), adj.values().double(), (n, n)), B.double())
     assert ((Z.double() - exact).abs() <= 1e-5 * exact).all()
@@ -760,3 +765,85 @@ def test_bundle_plan_matches_the_oracle(n, m, nnz, hubs, F, nstage, piece, R, al
         over = torch.full((n, F), float('nan'), device=dev)
         spmm_cpp.spmm_plan(blk, Bp, over, alpha, 1.0, plan, overwrite=True)
         assert torch.equal(over, Cg)
+
+
+@pytest.mark.parametrize('n,m,nnz,hubs,F,min_count,min_cols,piece,rest,alpha,beta', [
+    (3000, 5000, 250000, 3, 256, 4, 8, 64, 'runs', 1.0, 1.0), (2500, 4000, 200000, 2, 602, 5, 16, 1024, 'bundle', 1.0, 0.0),
+    (1501, 9000, 150000, 2, 128, 3, 8, 8, 'runs', 0.5, 2.0), (4003, 1200, 120000, 0, 100, 6, 32, 256, 'bundle', 1.0, 1.0),
+    (70, 700, 20000, 1, 130, 3, 8, 1024, 'runs', -1.0, 1.0), (2001, 3000, 160000, 2, 41, 4, 8, 128, 'runs', 1.0, 0.0)])
+def test_dense_tiles_plus_remainder_match_the_oracle(n, m, nnz, hubs, F, min_count, min_cols, piece, rest, alpha, beta):
+    """Dense tiles (dgnn_spmm_dense_f32, spmm_cpp.DensePlan / HybridPlan): the columns that several of a tile's 32 rows
+    share are multiplied as a dense [columns x 32] block (absent entries weigh 0), the other entries go through the
+    sparse plan first. Every element meets the fp64 bound; rows in no tile carry the oracle's bits; rows of uncut tiles
+    carry the bits of the oracle run on the plan's entry order (remainder ascending, then the listed columns ascending);
+    beta = 0 overwrites a NaN-filled C; widths that are no multiple of the 128-float chunk; same bits from run to run."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(n + F + min_count)
+    row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
+    fold = rng.random(col.size) < 0.6                                    # popular columns, so that rows share some
+    col = np.where(fold, col % 150, col).astype(np.int32)
+    key = np.unique(row.astype(np.int64) * m + col)
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    val = rng.random(key.size, dtype=np.float32) - 0.3
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if beta == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), alpha, beta)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    D = spmm_cpp.DensePlan(blk, min_count, min_cols, piece, keep_mask=True)
+    assert D.nk > 0 and 0.1 < D.share < 1.0 and D.rest.nnz + int(D.in_dense.sum()) == blk.nnz
+    rp = spmm_cpp.BundlePlan(D.rest, 2, 4, 256) if rest == 'bundle' else spmm_cpp.SegPlan(D.rest, 2, 256)
+    plan = spmm_cpp.HybridPlan(D, rp)
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+    Cg = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, Cg, alpha, beta, plan)
+    got = Cg.cpu().numpy()
+    assert np.isfinite(got).all()
+    rowptr = ref_cpu.coo2csr(row, n)
+    _check(got, want, rowptr, col, val, B, np.nan_to_num(C0), alpha, beta)               # fp64 bound on every element
+    strict = plan.strict_rows().cpu().numpy()
+    assert np.array_equal(got[strict], want[strict])
+    in_dense = D.in_dense.cpu().numpy()
+    perm = np.argsort(row.astype(np.int64) * 2 + in_dense, kind='stable')                # per row: remainder first, then the tiles' entries
+    want_perm = ref_cpu.spmm_csr(rowptr, col[perm], val[perm], B, C0.copy(), alpha, beta)
+    uncut = plan.uncut_rows().cpu().numpy()
+    touched = D.touched_rows().cpu().numpy()
+    assert (uncut & touched).sum() > 0 or piece <= 8
+    assert np.array_equal(got[uncut], want_perm[uncut])
+    again = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, again, alpha, beta, plan)
+    assert torch.equal(again, Cg)
+    if beta == 0.0:
+        over = torch.full((n, F), float('nan'), device=dev)
+        spmm_cpp.spmm_plan(blk, Bp, over, alpha, 1.0, plan, overwrite=True)
+        assert torch.equal(over, Cg)
+    # a C whose leading dimension is wider than F and not a multiple of 4 (scalar / float2 stores at the edge)
+    wide = torch.full((n, F + 3), 7.0, device=dev)
+    view = wide[:, :F]
+    view.copy_(torch.from_numpy(np.nan_to_num(C0)).to(dev))
+    spmm_cpp.spmm_plan(blk, Bp, view, alpha, 0.0 if beta == 0.0 else beta, plan)
+    assert torch.equal(view, Cg) and (wide[:, F:] == 7.0).all()
+
+
+def test_dense_entry_point_rejects_bad_arguments():
+    import spmm_cpp
+    lib = spmm_cpp.lib
+    lib.dgnn_last_error.restype = ctypes.c_char_p
+    rc = lib.dgnn_spmm_dense_f32(None, 1, 1, None, ctypes.c_int64(4), None, ctypes.c_int64(4), None, ctypes.c_int64(4), 4,
+                                 ctypes.c_float(1), None)
+    assert rc == 1 and b'null plan' in lib.dgnn_last_error()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5)
+    row, col, val = _rand_csr(rng, 200, 300, 20000)
+    blk = _gpu_block(row, col, val, 200, 300)
+    D = spmm_cpp.DensePlan(blk, 3, 8, 64)
+    assert D.nk > 0
+    B = torch.rand(300, 130, device=dev)                                     # rows not 16-byte aligned: refused
+    C = torch.zeros(200, 130, device=dev)
+    with pytest.raises(RuntimeError, match='ldb % 4'):
+        spmm_cpp.spmm_dense(D, B, C)
+    with pytest.raises(ValueError):
+        spmm_cpp.DensePlan(blk, 3, 8, 100)                                   # piece length must be a multiple of 8

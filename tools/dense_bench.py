@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--piece', default='1024')
     ap.add_argument('--rest', default='auto', help='plan of the remainder: auto | bundle | runs')
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--rest-stages', default='0', help='column-block stages of the remainder plan (0 = the rule)')
     ap.add_argument('--variants', default='', help='library debug variants to time the tile kernel with (results are wrong)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -58,30 +59,31 @@ def main():
                       f'{D.npiece} pieces, {D.npartial} partial rows, {D.nbytes/1e9:.2f} GB; remainder nnz {D.rest.nnz/1e6:.1f} M', flush=True)
                 for F in Fs:
                     Bp, C0 = ref[F]
-                    if args.rest == 'auto':
-                        rp = spmm_cpp._plan_for_sparse(D.rest, F)
-                    elif args.rest == 'bundle':
-                        rp = spmm_cpp.BundlePlan(D.rest, spmm_cpp.bundle_stage_count(A.n, A.m, D.rest.nnz, F), 4)
-                    else:
-                        rp = spmm_cpp.SegPlan(D.rest, spmm_cpp.default_stage_count(A.n, A.m, D.rest.nnz, F))
-                    hp = spmm_cpp.HybridPlan(D, rp)
-                    C = torch.full((A.n, F), float('nan'), device=dev)
-                    spmm_cpp.spmm_plan(A, Bp, C, 1.0, 0.0, hp)
-                    err = ((C - C0).abs().max() / C0.abs().max()).item()
-                    same = (C == C0).all(dim=1)
-                    ok = bool(same[hp.strict_rows()].all())
-                    med, best = time_call(lambda: spmm_cpp.spmm_plan(A, Bp, C, 1.0, 1.0, hp), args.iters, 2)
-                    md, _ = time_call(lambda: spmm_cpp.spmm_dense(D, Bp, C, 1.0), args.iters, 2)
-                    for v in [int(x) for x in args.variants.split(',') if x]:
-                        spmm_cpp.set_variant(v)
-                        mv, _ = time_call(lambda: spmm_cpp.spmm_dense(D, Bp, C, 1.0), args.iters, 2)
-                        print(f'    variant {v}: tiles {mv:.3f} ms', flush=True)
-                    spmm_cpp.set_variant(0)
-                    mr, _ = time_call(lambda: spmm_cpp.spmm_plan(D.rest, Bp, C, 1.0, 1.0, rp), args.iters, 2)
-                    ur = getattr(rp, 'union_ratio', 1.0)
-                    print(f'F={F:4d} tiles + {type(rp).__name__:10s}: {med:8.3f} ms (best {best:.3f}) = tiles {md:.3f} + rest {mr:.3f} (rest gathers {ur:.3f} of its nnz); '
-                          f'whole block {base[F]:.3f}; relerr {err:.1e}; rows with the strict chain\'s bits {int(same.sum())}/{A.n} (every strict row: {ok})', flush=True)
-                    del rp, hp
+                    for rs in [int(x) for x in args.rest_stages.split(',')]:
+                        if args.rest == 'auto' and not rs:
+                            rp = spmm_cpp._plan_for_sparse(D.rest, F)
+                        elif args.rest == 'bundle':
+                            rp = spmm_cpp.BundlePlan(D.rest, rs or spmm_cpp.bundle_stage_count(A.n, A.m, D.rest.nnz, F), 4)
+                        else:
+                            rp = spmm_cpp.SegPlan(D.rest, rs or spmm_cpp.default_stage_count(A.n, A.m, D.rest.nnz, F))
+                        hp = spmm_cpp.HybridPlan(D, rp)
+                        C = torch.full((A.n, F), float('nan'), device=dev)
+                        spmm_cpp.spmm_plan(A, Bp, C, 1.0, 0.0, hp)
+                        err = ((C - C0).abs().max() / C0.abs().max()).item()
+                        same = (C == C0).all(dim=1)
+                        ok = bool(same[hp.strict_rows()].all())
+                        med, best = time_call(lambda: spmm_cpp.spmm_plan(A, Bp, C, 1.0, 1.0, hp), args.iters, 2)
+                        md, _ = time_call(lambda: spmm_cpp.spmm_dense(D, Bp, C, 1.0), args.iters, 2)
+                        for v in [int(x) for x in args.variants.split(',') if x]:
+                            spmm_cpp.set_variant(v)
+                            mv, _ = time_call(lambda: spmm_cpp.spmm_dense(D, Bp, C, 1.0), args.iters, 2)
+                            print(f'    variant {v}: tiles {mv:.3f} ms', flush=True)
+                        spmm_cpp.set_variant(0)
+                        mr, _ = time_call(lambda: spmm_cpp.spmm_plan(D.rest, Bp, C, 1.0, 1.0, rp), args.iters, 2)
+                        ur = getattr(rp, 'union_ratio', 1.0)
+                        print(f'F={F:4d} tiles + {type(rp).__name__:10s} ns={rp.nstage}: {med:8.3f} ms (best {best:.3f}) = tiles {md:.3f} + rest {mr:.3f} (rest gathers {ur:.3f} of its nnz); '
+                              f'whole block {base[F]:.3f}; relerr {err:.1e}; rows with the strict chain\'s bits {int(same.sum())}/{A.n} (every strict row: {ok})', flush=True)
+                        del rp, hp
                 del D
 
 

@@ -24,7 +24,7 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'lib', 'libdgnn_spmm.so')
+_LIB_PATH = os.environ.get('DGNN_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'lib', 'libdgnn_spmm.so')   # DGNN_LIB: A/B runs of two builds
 if not os.path.exists(_LIB_PATH):
     raise RuntimeError(
         f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is missing -- build it with '

@@ -148,13 +148,14 @@ def cpu_baseline(g, widths, budget_s, rank_rows):
 def cpu_epoch_baseline(workload, budget_s):
     """Epoch time of the reference's CPU configuration (gloo, CPU tensors, SpMM = its fallback ``C.addmm_(A, B)``,
     SURVEY 8d) on the box's host cores: tools/cpu_epoch.py in child processes that never touch the GPU. Cora shape at
-    P = 1 and 2 (BASELINE configs[0]); the bench workload's shape at 1/10 of its nodes (same density) at P = 1 -- the
+    P = 1 and 2 (BASELINE configs[0]); the bench workload's shape at 1/10 of its nodes (same density) at P = 1 and 8 -- the
     full-size graph would take minutes per epoch on the host. Bounded: each child has a time limit."""
     import subprocess
     cores = host_threads()
     runs = [('cora', 1.0, 1, 3), ('cora', 1.0, 2, 3)]
     if workload in ('reddit', 'products'):
-        runs.append((workload, 0.1 if workload == 'reddit' else 0.03, 1, 1))
+        sc = 0.1 if workload == 'reddit' else 0.03
+        runs += [(workload, sc, 1, 1), (workload, sc, 8, 1)]           # SURVEY 8d: P = 1 and P = 8 processes, cores // P threads each
     out = []
     for wl, scale, P, epochs in runs:
         cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_epoch.py'), '--workload', wl, '--scale', str(scale),

@@ -865,21 +865,21 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
     };
     f32x2 pf = touch(k0 + DENSE_PF - 4);
     f32x2 b0 = slice(k0), b1 = slice(k0 + 1), b2 = slice(k0 + 2), b3 = slice(k0 + 3);
-    f32x2 n0, n1, n2, n3;
+    f32x2 n0 = b0, n1 = b1, n2 = b2, n3 = b3;
 #define DENSE_TRIP(K, B0, B1, B2, B3, N0, N1, N2, N3)                                         \
     {                                                                                         \
       const float* const a0 = kval + (int64_t)((DBG & 1) ? ((K) & 63) : (K)) * DENSE_TR;      \
       const int kn = min((K) + 4, k1 - 4);                                                    \
       dense_fma<ALPHA1>(acc, a0, B0, alpha, 0, NP);                                           \
-      N0 = slice(kn);                                                                         \
+      if (!(DBG & 8)) N0 = slice(kn);                                                         \
       dense_fma<ALPHA1>(acc, a0 + DENSE_TR, B1, alpha, 0, NP);                                \
-      N1 = slice(kn + 1);                                                                     \
+      if (!(DBG & 8)) N1 = slice(kn + 1);                                                                     \
       asm volatile("" ::"v"(pf));          /* last trip's touch has landed (no instruction) */ \
-      pf = touch((K) + DENSE_PF);                                                             \
+      if (!(DBG & 4)) pf = touch((K) + DENSE_PF);                                             \
       dense_fma<ALPHA1>(acc, a0 + 2 * DENSE_TR, B2, alpha, 0, NP);                            \
-      N2 = slice(kn + 2);                                                                     \
+      if (!(DBG & 8)) N2 = slice(kn + 2);                                                                     \
       dense_fma<ALPHA1>(acc, a0 + 3 * DENSE_TR, B3, alpha, 0, NP);                            \
-      N3 = slice(kn + 3);                                                                     \
+      if (!(DBG & 8)) N3 = slice(kn + 3);                                                                     \
     }
 #pragma unroll 1
     for (int k = k0; k < k1; k += 8) {                         // k1 - k0 is a multiple of 8 (lists are padded)
@@ -1672,6 +1672,9 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
     else if (g_variant == 301) DGNN_DENSE(true, 1);
     else if (g_variant == 302) DGNN_DENSE(true, 2);
     else if (g_variant == 303) DGNN_DENSE(true, 3);
+    else if (g_variant == 307) DGNN_DENSE(true, 7);
+    else if (g_variant == 311) DGNN_DENSE(true, 11);
+    else if (g_variant == 315) DGNN_DENSE(true, 15);
     else DGNN_DENSE(true, 0);
 #undef DGNN_DENSE
     DGNN_HIP(hipGetLastError());

@@ -358,7 +358,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         os.environ['DGNN_TRANSFORM_FIRST'] = '0'
         alt = dict(transform_first_ms_per_step=round(float(t.item()) / k_alt * 1e3, 3), steps=k_alt,
-                   note='opt-in DGNN_TRANSFORM_FIRST=1, same model and data; not the headline')
+                   note='opt-in DGNN_TRANSFORM_FIRST=1 / DGNN_WGRAD_FROM_Z=1 (layer 1 takes dW = Z^T G from its kept forward '
+                        'aggregation: one SpMM less) / both; same model and data; not the headline')
+        for key, tf in (('wgrad_from_z_ms_per_step', '0'), ('both_ms_per_step', '1')):
+            os.environ['DGNN_WGRAD_FROM_Z'], os.environ['DGNN_TRANSFORM_FIRST'] = '1', tf
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(k_alt):
+                step()
+            torch.cuda.synchronize()
+            alt[key] = round((time.perf_counter() - ta) / k_alt * 1e3, 3)
+        os.environ['DGNN_WGRAD_FROM_Z'], os.environ['DGNN_TRANSFORM_FIRST'] = '0', '0'
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         cpu = cpu_baseline(g, widths, args.cpu_budget, s)

@@ -774,6 +774,16 @@ def transform_first():
     return os.environ.get('DGNN_TRANSFORM_FIRST', '0') == '1'
 
 
+def wgrad_from_z():
+    """DGNN_WGRAD_FROM_Z=1 (opt-in): a layer whose INPUT needs no gradient (layer 1: the dataset's features) keeps its
+    forward aggregation Z = A_hat H and takes the weight gradient as Z^T G -- the exact derivative of out = Z W --
+    instead of aggregating the output gradient first, H^T (A_hat G) (gcn.py:47-50). One SpMM and one feature-block
+    exchange less per epoch. The two agree when A_hat is symmetric (the reference's own assumption, gcn.py:47), in a
+    different fp32 association (<= 1e-5 relative, tested); on an asymmetric graph this is the TRUE gradient while the
+    reference's formula is not, so it is off by default (the compat default reproduces the reference there too)."""
+    return os.environ.get('DGNN_WGRAD_FROM_Z', '0') == '1'
+
+
 def broadcast(local_adj_parts, local_feature, tag, padded_out=False):
     """z_loc = sum over src of A[rank, src] @ H_src  (new [s, F] tensor), gcn.py:16-30."""
     return pipeline().run(local_adj_parts, local_feature, tag, padded_out=padded_out)
@@ -800,12 +810,22 @@ class DistGCNLayer(torch.autograd.Function):
                 hw = torch.mm(features, weight)
             return broadcast(adj_parts, hw, 'Forward' + tag + 'T')
         z_local = broadcast(adj_parts, features, 'Forward' + tag, padded_out=True)
+        if wgrad_from_z() and not ctx.needs_input_grad[0]:
+            ctx.z_local = z_local                       # kept instead of re-deriving A_hat G in the backward pass
         with timer.timing_cuda('mm'):
             return torch.mm(z_local, weight)
 
     @staticmethod
     def backward(ctx, grad_output):
         features, weight = ctx.saved_tensors
+        z_local = getattr(ctx, 'z_local', None)
+        if z_local is not None:                         # opt-in: dW = Z^T G, no aggregation of the output gradient
+            ctx.z_local = None
+            with DistEnv.env.timer.timing_cuda('mm'):
+                grad_weight = grad_weight_product(z_local, grad_output)
+            with DistEnv.env.timer.timing_cuda('all_reduce'):
+                DistEnv.env.all_reduce_sum(grad_weight)
+            return None, grad_weight, None, None
         blocks = getattr(ctx.adj_parts, 'transposed', None) or ctx.adj_parts
         ag = broadcast(blocks, grad_output, 'Backward' + ctx.tag, padded_out=True)
         with DistEnv.env.timer.timing_cuda('mm'):

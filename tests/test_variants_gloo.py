@@ -196,6 +196,52 @@ def scenario_transform_first(env, rank, world, gold_dir):
                 wide=g.features.size(1))
 
 
+def scenario_wgrad_from_z(env, rank, world, gold_dir):
+    """DGNN_WGRAD_FROM_Z=1: layer 1 (input without gradient) takes dW = Z^T G from its kept forward aggregation."""
+    import coo_graph
+    from models import gcn
+    res = {}
+    for name in ('tiny', 'directed'):
+        gold = np.load(os.path.join(gold_dir, f'{name}_graph.npz'))
+        full = coo_graph.COO_Graph(name, attr_dict=_raw(gold))
+        g = coo_graph.Parted_COO_Graph(name, rank, world, attr_dict=full.partition(world, save=False)[rank])
+        torch.manual_seed(3)
+        W = torch.rand(g.features.size(1), 5)
+        G = torch.rand(g.local_num_nodes, 5)
+        out = {}
+        for flag in ('0', '1'):
+            os.environ['DGNN_WGRAD_FROM_Z'] = flag
+            Wp = W.clone().requires_grad_(True)
+            t0 = gcn.pipeline().transfers
+            y = gcn.DistGCNLayer.apply(g.features, Wp, g.adj_parts, 'L1')      # the features need no gradient
+            y.backward(G)
+            out[flag] = (y.detach().double(), Wp.grad.double(), gcn.pipeline().transfers - t0)
+            Xg = g.features.clone().requires_grad_(True)                          # an input that needs one: unchanged path
+            Wq = W.clone().requires_grad_(True)
+            gcn.DistGCNLayer.apply(Xg, Wq, g.adj_parts, 'L2').backward(G)
+            out[flag] += (Xg.grad.double(), Wq.grad.double())
+        os.environ['DGNN_WGRAD_FROM_Z'] = '0'
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+        res[name] = dict(out=rel(out['1'][0], out['0'][0]), dw=rel(out['1'][1], out['0'][1]),
+                         transfers=(out['0'][2], out['1'][2]),
+                         dx_same=bool(torch.equal(out['1'][3], out['0'][3])), dw2_same=bool(torch.equal(out['1'][4], out['0'][4])),
+                         true=_true_wgrad(full, g, W, G, env, rank, world, out['1'][1]))
+    return res
+
+
+def _true_wgrad(full, g, W, G, env, rank, world, got):
+    """|got - (A_hat X)^T G| / max, with G gathered over the ranks (fp64)."""
+    import torch.distributed as dist
+    gs = [torch.zeros_like(G) for _ in range(world)]
+    dist.all_gather(gs, G)
+    Gall = torch.cat(gs).double()
+    X = full.features.double()
+    n = X.size(0)
+    Z = full.adj.to_dense().double() @ X
+    true = Z.t() @ Gall[:n]
+    return float((got - true).abs().max() / true.abs().max())
+
+
 def scenario_needed_rows(env, rank, world, gold_dir):
     """A sparse random graph (most columns of a block empty): needed-rows transfer vs whole blocks."""
     import coo_graph
@@ -312,6 +358,22 @@ def test_transform_first_is_the_same_layer(tmp_path):
         assert res['wide'] > 5
         assert 0 < res['out'] <= 1e-5, res            # re-associated (not bit-equal), within the 1e-5 bar
         assert res['dx'] == 0.0 and res['dw'] == 0.0, res
+
+
+def test_weight_gradient_from_the_kept_aggregation(tmp_path):
+    """Opt-in DGNN_WGRAD_FROM_Z: same output bits, one aggregation (P transfers) less, the weight gradient within fp32
+    re-association of the reference formula on the symmetric graph and equal to the true gradient (A_hat X)^T G on
+    both -- on the asymmetric fixture the reference's own formula is NOT the true gradient, which is why this stays
+    opt-in; layers whose input needs a gradient are untouched."""
+    out = _run(2, 'wgrad_from_z', str(tmp_path))
+    for r, res in out.items():
+        for name in ('tiny', 'directed'):
+            d = res[name]
+            assert d['out'] == 0.0 and d['dx_same'] and d['dw2_same'], d
+            assert d['transfers'][1] < d['transfers'][0], d
+            assert d['true'] <= 1e-6, d
+        assert 0 <= res['tiny']['dw'] <= 1e-5, res
+        assert res['directed']['dw'] > 1e-3, res            # the compat formula differs from the true gradient there
 
 
 def test_needed_rows_transfer_is_bit_identical(tmp_path):

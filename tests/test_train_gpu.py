@@ -175,3 +175,32 @@ def test_csr_blocks_from_the_part_file_are_used(env, golden_dir, tmp_path, monke
         for src in range(3):
             gcn.spmm(pg.adj_parts[src], feats[src], z)
         assert np.array_equal(z.cpu().numpy(), w[f'r{r}_layer_z'])
+
+
+def test_weight_gradient_from_the_kept_aggregation_on_gpu(env, golden_dir):
+    """Opt-in DGNN_WGRAD_FROM_Z with the HIP kernels: layer 1 (input without gradient) takes dW = Z^T G from its kept
+    forward aggregation -- no backward SpMM at all (the timer's spmm count says so) -- and lands within 1e-5 of the
+    reference's golden weight gradient (symmetric graph); the loss curve of a training run is unchanged to 1e-4."""
+    import coo_graph
+    import dist_train
+    from models import gcn
+    g = np.load(os.path.join(golden_dir, 'tiny_graph.npz'))
+    w = np.load(os.path.join(golden_dir, 'tiny_P1.npz'))
+    dev = env.device
+    full = coo_graph.COO_Graph('tiny', attr_dict=_raw(g, dev), device=dev)
+    pg = coo_graph.Parted_COO_Graph('tiny', 0, 1, device=dev, attr_dict=full.partition(1, save=False)[0])
+    pg.features = torch.from_numpy(w['r0_features']).to(dev)
+    os.environ['DGNN_WGRAD_FROM_Z'] = '1'
+    try:
+        W = torch.from_numpy(w['r0_layer_W']).to(dev).requires_grad_(True)
+        before = env.timer.count_dict.get('spmm', 0)
+        y = gcn.DistGCNLayer.apply(pg.features, W, pg.adj_parts, 'L1')
+        y.backward(torch.from_numpy(w['r0_layer_grad_out']).to(dev))
+        assert env.timer.count_dict.get('spmm', 0) - before == 1                      # the forward aggregation only
+        for got, key in ((y, 'layer_out'), (W.grad, 'layer_grad_weight')):
+            want = w['r0_' + key]
+            assert np.abs(got.detach().cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max(), key
+        losses = dist_train.train(pg, env, total_epoch=5)
+        np.testing.assert_allclose(np.array(losses), w['r0_losses'], rtol=1e-4, atol=1e-4)
+    finally:
+        os.environ['DGNN_WGRAD_FROM_Z'] = '0'

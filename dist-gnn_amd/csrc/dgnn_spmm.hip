@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void spmm_stage_kernel(
 
   const uint32_t nb = gridDim.x, b = blockIdx.x;
   const uint32_t q = nb >> 3, r = nb & 7, xcd = b & 7;
-  const uint32_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  // k == 0 (experiment, variant 404-407): plain chunk-major order -- every XCD works on the same feature chunk at
+  // the same time (the Infinity Cache then sees one chunk of B instead of all of them)
+  const uint32_t w = k == 0 ? b : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   const uint32_t chunk = w / nsegblocks;
   // Inside a chunk the segment blocks are listed longest first, and an XCD's share of the work index is
   // a contiguous range that may cover a fraction of a chunk -- which must not be "the long ones".
@@ -1239,8 +1241,9 @@ int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_
   const int64_t nchunks = (ldb / 4 + L - 1) / L;
   int64_t gcd8 = 8;
   while (nchunks % gcd8) gcd8 >>= 1;
-  const uint32_t k = g_variant == 3 ? 1u : (uint32_t)(8 / gcd8);       // classes per chunk (see the kernel)
+  uint32_t k = g_variant == 3 ? 1u : (uint32_t)(8 / gcd8);             // classes per chunk (see the kernel)
   nsegblocks = (nsegblocks + k - 1) / k * k;                           // equal classes; tail blocks idle
+  if (g_variant >= 404 && g_variant < 408) k = 0;
   const int64_t nb = nsegblocks * nchunks;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "stage grid out of range%s (%lld)", "", nb);
   ProfScope prof(s, 0);
@@ -1734,6 +1737,7 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
       // better for narrow blocks only while XCD shares were unbalanced (more chunks hid it); with balanced
       // shares they are 5-25 % slower at every width measured. Kept behind the variant knob for A/B runs.
       const bool narrow = (g_variant == 8);
+      const int lsel = (g_variant >= 400 && g_variant < 408) ? (g_variant & 3) : 0;     // experiments: 1 -> 8, 2 -> 16, 3 -> 32 lanes
       if (plan->hot_rows > 0) {
         if ((plan->hot_rows != 256 && plan->hot_rows != 512) || !plan->hot_cols || !plan->seg_hot)
           return fail(DGNN_E_BADARG, "spmm_plan: hot-tile plan needs hot_rows 256 or 512, hot_cols and seg_hot%s", "");
@@ -1746,6 +1750,8 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
 #undef DGNN_LAUNCH_HOT
       } else if (narrow)
         rc = launch_stage<8, 8>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s);
+      else if (lsel == 1)
+        rc = launch_stage<8, 2>(vwc, wide, seg, ns, col, val, B, ldb, C, ldc, partial, ldp, F, alpha, fresh, s);
       else {
         // Gathers in flight per lane: 4 while one stage's slice of B fits the 256 MiB Infinity Cache, 2 when
         // the rows come out of HBM (measured: products/papers shapes -6..-10 % with 2, Reddit -4 % with 4
@@ -1753,7 +1759,7 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
         const int64_t stage_bytes = (int64_t)(m / plan->nstage + 1) * ldb * 4;
         // A plan that leaves very long runs whole (the plan-less reference call) is bound by the serial walk
         // of its longest run: there, 8 in flight.
-        const bool wide_group = g_variant == 32 || (g_variant != 16 && ldb >= 256);   // 512-B slices from 256 floats up
+        const bool wide_group = lsel ? lsel == 3 : (g_variant == 32 || (g_variant != 16 && ldb >= 256));   // 512-B slices from 256 floats up
         // ... and 8 again when the launch is small (under ~200 K lane groups: the blocks of a 4- or 8-rank
         // partition, or one-chunk-wide features): few waves per CU, so each must keep more in flight and
         // the longest pieces set the time (measured -2..-25 %).

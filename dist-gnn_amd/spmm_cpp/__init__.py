@@ -685,7 +685,7 @@ class BundlePlan:
         ukey, inv = torch.unique(gb * m + col, return_inverse=True)                   # sorted: by bundle, then column
         nu = int(ukey.numel())
         ub = ukey // m
-        self.ucol = (ukey % m).int().contiguous()
+        self.ucol = (ukey % m).int().contiguous() if nu else torch.zeros(1, dtype=torch.int32, device=dev)   # never a null pointer
         del ukey
         uval = torch.zeros(max(nu, 1) * R, dtype=torch.float32, device=dev)
         uval[inv * R + rnk % R] = A.val

@@ -152,3 +152,69 @@ def test_device_built_plan_covers_every_nonzero_once(n, m, density, hubs, nstage
     assert (seen0 == 1).all(), 'the first stage must store every row exactly once'
     assert sum(pieces_seen.values()) == npart == len(pieces_seen) and npart <= lay.npartial_max
     assert ncut == int((cut[:, :, 2] > 0).sum())
+
+
+@st.composite
+def _shared_column_cases(draw):
+    n = draw(st.integers(1, 600))
+    m = draw(st.integers(8, 900))
+    return dict(n=n, m=m, nnz=int(n * m * draw(st.sampled_from([0.01, 0.05, 0.2]))),
+                F=draw(st.one_of(st.integers(1, 70), st.sampled_from([100, 128, 130, 172, 256, 300, 602]))),
+                fold=draw(st.sampled_from([0.0, 0.5, 0.9])), popular=draw(st.integers(1, 200)),
+                hubs=draw(st.integers(0, 2)), nstage=draw(st.integers(1, 5)),
+                piece=draw(st.sampled_from([8, 16, 64, 256, 4096])), R=draw(st.sampled_from([2, 4, 6, 8])),
+                min_count=draw(st.integers(1, 8)), min_cols=draw(st.sampled_from([1, 8, 40])),
+                rest=draw(st.sampled_from(['runs', 'bundle'])),
+                alpha=draw(st.sampled_from([1.0, 1.0, 0.5, -2.0])), beta=draw(st.sampled_from([1.0, 1.0, 0.0, 0.25])),
+                pad_c=draw(st.sampled_from([0, 1, 2, 4])), seed=draw(st.integers(0, 2 ** 20)))
+
+
+@settings(max_examples=200, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(_shared_column_cases())
+def test_bundle_and_dense_tile_forms_match_the_oracle(c):
+    """Row bundles and dense tiles + remainder on random blocks whose rows share columns to a random degree: the fp64
+    bound on every element, the oracle's bits on every row the plan leaves whole (bundles: rows of uncut bundles;
+    tiles: rows in no tile), nothing written past column F, beta = 0 never reads C."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(c['seed'])
+    n, m, F = c['n'], c['m'], c['F']
+    row, col, val = _rand_csr(rng, n, m, c['nnz'], hub_rows=c['hubs'])
+    if c['fold'] and row.size:
+        fold = rng.random(col.size) < c['fold']
+        col = np.where(fold, col % min(c['popular'], m), col).astype(np.int32)
+        key = np.unique(row.astype(np.int64) * m + col)
+        row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+        val = rng.random(key.size, dtype=np.float32) - 0.3
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if c['beta'] == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), c['alpha'], c['beta'])
+    rowptr = ref_cpu.coo2csr(row, n)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+
+    def run(plan):
+        buf = torch.full((n, F + c['pad_c']), 7.0, device=dev)
+        buf[:, :F] = torch.from_numpy(C0).to(dev)
+        spmm_cpp.spmm_plan(blk, Bp, buf[:, :F], c['alpha'], c['beta'], plan)
+        assert (buf[:, F:] == 7.0).all(), 'nothing may be written past column F'
+        got = buf[:, :F].cpu().numpy()
+        _check(got, want, rowptr, col, val, B, np.nan_to_num(C0), c['alpha'], c['beta'])
+        return got
+
+    bundle = spmm_cpp.BundlePlan(blk, c['nstage'], c['R'], c['piece'])
+    got = run(bundle)
+    whole = bundle.uncut_rows().cpu().numpy()
+    assert np.array_equal(got[whole], want[whole])
+
+    D = spmm_cpp.DensePlan(blk, c['min_count'], c['min_cols'], c['piece'])
+    rest = (spmm_cpp.BundlePlan(D.rest, c['nstage'], 4, max(c['piece'], 16)) if c['rest'] == 'bundle'
+            else spmm_cpp.SegPlan(D.rest, c['nstage'], c['piece']))
+    hybrid = spmm_cpp.HybridPlan(D, rest)
+    got = run(hybrid)
+    strict = hybrid.strict_rows().cpu().numpy()
+    assert np.array_equal(got[strict], want[strict])
+    assert D.rest.nnz + round(D.share * blk.nnz) == blk.nnz

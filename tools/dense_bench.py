@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--piece', default='1024')
     ap.add_argument('--rest', default='auto', help='plan of the remainder: auto | bundle | runs')
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--rest-variants', default='', help='library variants to time the remainder plan with (102..108: gathers in flight)')
     ap.add_argument('--rest-stages', default='0', help='column-block stages of the remainder plan (0 = the rule)')
     ap.add_argument('--variants', default='', help='library debug variants to time the tile kernel with (results are wrong)')
     args = ap.parse_args()
@@ -80,6 +81,11 @@ def main():
                             print(f'    variant {v}: tiles {mv:.3f} ms', flush=True)
                         spmm_cpp.set_variant(0)
                         mr, _ = time_call(lambda: spmm_cpp.spmm_plan(D.rest, Bp, C, 1.0, 1.0, rp), args.iters, 2)
+                        for v in [int(x) for x in args.rest_variants.split(',') if x]:
+                            spmm_cpp.set_variant(v)
+                            mv, _ = time_call(lambda: spmm_cpp.spmm_plan(D.rest, Bp, C, 1.0, 1.0, rp), args.iters, 2)
+                            print(f'    rest variant {v}: {mv:.3f} ms', flush=True)
+                        spmm_cpp.set_variant(0)
                         ur = getattr(rp, 'union_ratio', 1.0)
                         print(f'F={F:4d} tiles + {type(rp).__name__:10s} ns={rp.nstage}: {med:8.3f} ms (best {best:.3f}) = tiles {md:.3f} + rest {mr:.3f} (rest gathers {ur:.3f} of its nnz); '
                               f'whole block {base[F]:.3f}; relerr {err:.1e}; rows with the strict chain\'s bits {int(same.sum())}/{A.n} (every strict row: {ok})', flush=True)

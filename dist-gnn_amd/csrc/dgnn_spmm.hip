@@ -797,19 +797,19 @@ __device__ __forceinline__ void c2_store(float* p, int fbase, int F, bool vw2, f
 // one v_pk_fma_f32 as it stands, the lane's B value is the broadcast one (op_sel on a VGPR costs nothing), so
 // acc[j][e] = (C[row 2j][fbase + e], C[row 2j + 1][fbase + e]) and no scalar move is needed per value (the CU's one
 // scalar unit could not keep up with 32 of them per column).
-template <bool ALPHA1>
-__device__ __forceinline__ void dense_fma(f32x2 (&acc)[DENSE_TR / 2][2], const float* __restrict__ a, f32x2 b, float alpha, int j0, int j1) {
+// W = floats per lane: 2 (a 128-float chunk per wave) or 1 (64 floats: feature blocks at most 64 floats wide).
+template <bool ALPHA1, int W>
+__device__ __forceinline__ void dense_fma(f32x2 (&acc)[DENSE_TR / 2][W], const float* __restrict__ a, f32x2 b, float alpha) {
 #pragma unroll
   for (int j = 0; j < DENSE_TR / 2; ++j) {
-    if (j < j0 || j >= j1) continue;
     f32x2 a2 = {a[2 * j], a[2 * j + 1]};
     if (!ALPHA1) a2 = a2 * alpha;
     acc[j][0] = __builtin_elementwise_fma(a2, (f32x2){b.x, b.x}, acc[j][0]);
-    acc[j][1] = __builtin_elementwise_fma(a2, (f32x2){b.y, b.y}, acc[j][1]);
+    if constexpr (W == 2) acc[j][1] = __builtin_elementwise_fma(a2, (f32x2){b.y, b.y}, acc[j][1]);
   }
 }
 
-template <bool ALPHA1, int DBG>
+template <bool ALPHA1, int DBG, int W>
 __global__ __launch_bounds__(256) void spmm_dense_kernel(
     const int4* __restrict__ desc, int32_t nitems, int32_t nchunk,
     const int32_t* __restrict__ rows, const int32_t* __restrict__ kcol, const float* __restrict__ kval,
@@ -822,43 +822,42 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
   if (item >= nitems) return;                                // on `lane` lives in SGPRs
   const int piece = item / nchunk, chunk = item - piece * nchunk;
   const int4 d = desc[piece];                                // {k0, k1, tile, out}; k1 - k0 is a multiple of 8 (lists are padded)
-  const int fbase = chunk * 128 + lane * 2;
+  const int fbase = (chunk * 64 + lane) * W;
   const bool active = fbase < (int)ldb;                      // lanes past the padded width compute on column 0, store nothing
   const uint64_t ldb_bytes = (uint64_t)ldb * 4u;
   const uint32_t loff = active ? (uint32_t)fbase * 4u : 0u;
   const char* const Bb = reinterpret_cast<const char*>(B);
   const int32_t* const rw = rows + (int64_t)d.z * DENSE_TR;
   const bool direct = d.w < 0;
+  const bool v2 = W == 2 && vw2 != 0;
 
-  f32x2 acc[NP][2];
+  f32x2 acc[NP][W];                                          // acc[j][e] = (C[row 2j][fbase + e], C[row 2j + 1][fbase + e])
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     f32x2 c0 = {0.f, 0.f}, c1 = {0.f, 0.f};
     if (direct && active) {
       const int r0 = rw[2 * j], r1 = rw[2 * j + 1];
-      if (r0 >= 0) c0 = c2_load(C + (int64_t)r0 * ldc + fbase, fbase, F, vw2 != 0);
-      if (r1 >= 0) c1 = c2_load(C + (int64_t)r1 * ldc + fbase, fbase, F, vw2 != 0);
+      if (r0 >= 0) c0 = c2_load(C + (int64_t)r0 * ldc + fbase, fbase, W == 2 ? F : min(F, fbase + 1), v2);
+      if (r1 >= 0) c1 = c2_load(C + (int64_t)r1 * ldc + fbase, fbase, W == 2 ? F : min(F, fbase + 1), v2);
     }
     acc[j][0] = (f32x2){c0.x, c1.x};
-    acc[j][1] = (f32x2){c0.y, c1.y};
+    if constexpr (W == 2) acc[j][1] = (f32x2){c0.y, c1.y};
   }
 
   const int k0 = d.x, k1 = d.y;
   if (k0 < k1) {
-    // Two columns per trip, their value rows in two SGPR sets that are loaded in turn: the scalar load of one set is
-    // issued right after the first FMA of the other (scalar loads return out of order, so a wait covers everything
-    // outstanding: only one set may be in flight while the other is multiplied).
     const uint32_t ldb_lo = (uint32_t)ldb_bytes;             // ldb * 4 < 2^32 (checked by the launcher)
-    auto slice = [&](int k) -> f32x2 {                         // scalar row base (SALU) + 32-bit lane offset: saddr form
+    auto slice = [&](int k) -> f32x2 {                         // scalar row base (SALU) + 32-bit lane offset
       const uint32_t c = (DBG & 2) ? (uint32_t)(k & 63) : (uint32_t)kcol[k];
       const uint64_t off = ((uint64_t)__umulhi(c, ldb_lo) << 32) | (uint64_t)(c * ldb_lo);
-      return *reinterpret_cast<const f32x2*>(Bb + off + loff);
+      if constexpr (W == 2) return *reinterpret_cast<const f32x2*>(Bb + off + loff);
+      else return (f32x2){*reinterpret_cast<const float*>(Bb + off + loff), 0.f};
     };
-    // The value rows are a cold stream (HBM) and a scalar load cannot be issued far ahead (there are SGPRs for one
-    // trip's 64 values only), so every trip would wait out a memory latency with nothing but the other waves' FMAs
-    // to cover it (measured: 57 % of the FMA rate at 4 waves per SIMD). The wave therefore touches the 256 bytes of
-    // trip t + DENSE_PF with one coalesced vector load (a dword per lane) that nobody waits for until two trips later:
-    // when the scalar loads come, the lines are in L2.
+    // The value rows are a cold stream (HBM) and a scalar load cannot be issued far ahead (there are SGPRs for two
+    // columns' 64 values only), so every trip would wait out a memory latency with nothing but the other waves' FMAs
+    // to cover it (measured: 57 % of the FMA rate at 4 waves per SIMD). The wave therefore touches the 512 bytes of
+    // the trip DENSE_PF columns ahead with one coalesced vector load that nobody waits for until a trip later: when the
+    // scalar loads come, the lines are in L2.
     // Vector loads return in order, so a wait for a B slice also waits for every older load: the slices are fetched a
     // whole trip (4 columns) ahead and the touch goes out in the middle of a trip, which gives it a trip's time to land.
     constexpr int DENSE_PF = 16;                               // the touch runs this many columns ahead
@@ -872,16 +871,16 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
     {                                                                                         \
       const float* const a0 = kval + (int64_t)((DBG & 1) ? ((K) & 63) : (K)) * DENSE_TR;      \
       const int kn = min((K) + 4, k1 - 4);                                                    \
-      dense_fma<ALPHA1>(acc, a0, B0, alpha, 0, NP);                                           \
+      dense_fma<ALPHA1, W>(acc, a0, B0, alpha);                                               \
       if (!(DBG & 8)) N0 = slice(kn);                                                         \
-      dense_fma<ALPHA1>(acc, a0 + DENSE_TR, B1, alpha, 0, NP);                                \
-      if (!(DBG & 8)) N1 = slice(kn + 1);                                                                     \
+      dense_fma<ALPHA1, W>(acc, a0 + DENSE_TR, B1, alpha);                                    \
+      if (!(DBG & 8)) N1 = slice(kn + 1);                                                     \
       asm volatile("" ::"v"(pf));          /* last trip's touch has landed (no instruction) */ \
       if (!(DBG & 4)) pf = touch((K) + DENSE_PF);                                             \
-      dense_fma<ALPHA1>(acc, a0 + 2 * DENSE_TR, B2, alpha, 0, NP);                            \
-      if (!(DBG & 8)) N2 = slice(kn + 2);                                                                     \
-      dense_fma<ALPHA1>(acc, a0 + 3 * DENSE_TR, B3, alpha, 0, NP);                            \
-      if (!(DBG & 8)) N3 = slice(kn + 3);                                                                     \
+      dense_fma<ALPHA1, W>(acc, a0 + 2 * DENSE_TR, B2, alpha);                                \
+      if (!(DBG & 8)) N2 = slice(kn + 2);                                                     \
+      dense_fma<ALPHA1, W>(acc, a0 + 3 * DENSE_TR, B3, alpha);                                \
+      if (!(DBG & 8)) N3 = slice(kn + 3);                                                     \
     }
 #pragma unroll 1
     for (int k = k0; k < k1; k += 8) {                         // k1 - k0 is a multiple of 8 (lists are padded)
@@ -899,9 +898,14 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
     for (int h = 0; h < 2; ++h) {
       const int row = rw[2 * j + h];
       if (row < 0) continue;
-      const f32x2 v = h == 0 ? (f32x2){acc[j][0].x, acc[j][1].x} : (f32x2){acc[j][0].y, acc[j][1].y};
-      if (direct) c2_store(C + (int64_t)row * ldc + fbase, fbase, F, vw2 != 0, v);
-      else if (fbase < ldp) *reinterpret_cast<float2*>(P + (int64_t)(d.w + 2 * j + h) * ldp + fbase) = make_float2(v.x, v.y);
+      f32x2 v = {h == 0 ? acc[j][0].x : acc[j][0].y, 0.f};
+      if constexpr (W == 2) v.y = h == 0 ? acc[j][1].x : acc[j][1].y;
+      if (direct) c2_store(C + (int64_t)row * ldc + fbase, fbase, W == 2 ? F : min(F, fbase + 1), v2, v);
+      else if (fbase < ldp) {
+        float* const pp = P + (int64_t)(d.w + 2 * j + h) * ldp + fbase;
+        if constexpr (W == 2) *reinterpret_cast<float2*>(pp) = make_float2(v.x, v.y);
+        else *pp = v.x;
+      }
     }
   }
 }
@@ -1659,7 +1663,8 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
   if (overlap(B, m, ldb, C, n, ldc, F)) return fail(DGNN_E_BADARG, "spmm_dense: B and C overlap%s", "");
   if (ldb >= (1ll << 30)) return fail(DGNN_E_BADARG, "spmm_dense: ldb out of range%s", "");
   hipStream_t s = (hipStream_t)stream;
-  const int64_t nchunk = (ldb + 127) / 128;
+  const int w = ldb <= 64 ? 1 : 2;                           // floats per lane: a 64- or a 128-float chunk per wave
+  const int64_t nchunk = (ldb + 64 * w - 1) / (64 * w);
   const int64_t nitems = (int64_t)plan->npiece * nchunk;
   if (nitems > 0x7fffffffLL) return fail(DGNN_E_BADARG, "spmm_dense: grid out of range%s (%lld)", "", nitems);
   const int vw2 = (ldc % 2 == 0 && aligned(C, 8)) ? 1 : 0;
@@ -1668,17 +1673,18 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
     ProfScope prof(s, 0);
     const dim3 grid((unsigned)((nitems + 3) / 4));
     const int4* desc = reinterpret_cast<const int4*>(plan->desc);
-#define DGNN_DENSE(A1, W)                                                                                             \
-    hipLaunchKernelGGL((spmm_dense_kernel<A1, W>), grid, dim3(256), 0, s, desc, (int32_t)nitems, (int32_t)nchunk, plan->rows, \
+#define DGNN_DENSE(A1, D, WW)                                                                                          \
+    hipLaunchKernelGGL((spmm_dense_kernel<A1, D, WW>), grid, dim3(256), 0, s, desc, (int32_t)nitems, (int32_t)nchunk, plan->rows, \
                        plan->kcol, plan->kval, B, ldb, C, ldc, partial, ldp, F, alpha, vw2)
-    if (alpha != 1.f) DGNN_DENSE(false, 0);
-    else if (g_variant == 301) DGNN_DENSE(true, 1);
-    else if (g_variant == 302) DGNN_DENSE(true, 2);
-    else if (g_variant == 303) DGNN_DENSE(true, 3);
-    else if (g_variant == 307) DGNN_DENSE(true, 7);
-    else if (g_variant == 311) DGNN_DENSE(true, 11);
-    else if (g_variant == 315) DGNN_DENSE(true, 15);
-    else DGNN_DENSE(true, 0);
+    if (w == 1) { if (alpha != 1.f) DGNN_DENSE(false, 0, 1); else DGNN_DENSE(true, 0, 1); }
+    else if (alpha != 1.f) DGNN_DENSE(false, 0, 2);
+    else if (g_variant == 301) DGNN_DENSE(true, 1, 2);
+    else if (g_variant == 302) DGNN_DENSE(true, 2, 2);
+    else if (g_variant == 303) DGNN_DENSE(true, 3, 2);
+    else if (g_variant == 307) DGNN_DENSE(true, 7, 2);
+    else if (g_variant == 311) DGNN_DENSE(true, 11, 2);
+    else if (g_variant == 315) DGNN_DENSE(true, 15, 2);
+    else DGNN_DENSE(true, 0, 2);
 #undef DGNN_DENSE
     DGNN_HIP(hipGetLastError());
   }

@@ -510,7 +510,9 @@ def _plan_for(A, F):
     time -- what very large blocks want."""
     # Dense tiles (DensePlan): where a block holds a large share of its nonzeros in tiles of 32 rows x their common
     # columns (hub rows x hub columns), that part runs as register-tiled fp32 FMAs and the plans below are built for the
-    # sparse remainder. Feature blocks of at least 128 floats only (one wave = one 128-float chunk).
+    # sparse remainder. Feature blocks of at least 128 floats only: the tile kernel has a 64-float form too, but its cost
+    # is dominated by the value stream, which does not shrink with the width (Reddit shape, F = 41: tiles 0.63 + remainder
+    # 1.16 ms against 1.49 ms for the whole block on the stage kernel).
     if padded_width(F) >= 128 and not int(os.environ.get('DGNN_HOT_ROWS', 0) or 0) \
             and os.environ.get('DGNN_PLAN_BUILDER', 'torch') != 'device':
         D = _dense_for(A)

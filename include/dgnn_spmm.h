@@ -250,6 +250,7 @@ int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
  *                  slots), in working order; out < 0: the members accumulate into C, else the piece sums go to partial
  *                  rows out + r and are merged per row (cut list {row, first partial row, pieces, 31}, as in dgnn_plan)
  *   npartial       rows the partial buffer must hold
+ * One wave takes one piece and one chunk of 128 floats of the feature width (64 floats when ldb <= 64).
  * An output element is one chain of fused multiply-adds over the tile's list in ascending column order, continuing
  * from what C holds (a zero weight leaves it as it is for finite B): rows of uncut tiles carry the bits of the strict
  * chain over [remainder entries, then listed entries]; rows of cut tiles the fixed-order piece sums. No MFMA, no

@@ -6,7 +6,8 @@
 // B[j, :] through the cache hierarchy and fuses them into the accumulators of C[i, :]. There is
 // no MFMA here. What bounds it on MI355X is the vector-memory gather rate (L1/TA -> per-XCD L2
 // -> Infinity Cache -> HBM); the kernels below are organised around keeping gathers L2-resident
-// and many of them in flight. Two kernel families:
+// and many of them in flight -- and, where the block allows it, around paying fewer gathers per nonzero (row bundles,
+// dense tiles). Kernel families:
 //
 //   spmm_rows_kernel   general operands (any alignment / leading dimension). One group of L
 //                      lanes owns one output row; strictly ascending accumulation.
@@ -14,6 +15,11 @@
 //                      16-byte aligned (ldb % 4 == 0). Feature chunks of 64 or 128 floats,
 //                      XCD-aware chunk-major work order with balanced XCD shares, column-block
 //                      stages, long rows cut in pieces, 16- or 32-lane groups.
+//   spmm_bundle_kernel the same walk over the union of R rows' columns: one gather feeds up to R accumulators
+//                      (blocks whose rows share columns).
+//   spmm_dense_kernel  tiles of 32 rows x the columns several of them share, stored densely: one coalesced slice of a
+//                      B row feeds 32 rows' packed FMAs whose A operands come through the scalar data path (hub rows x
+//                      hub columns of power-law graphs); adds to what the sparse remainder of the block has written.
 //
 // In both, a (col, val) run of a row is read with coalesced loads, one entry per lane. The row
 // kernel hands entries lane-to-lane (v_readlane when L == 64, ds_bpermute otherwise); the

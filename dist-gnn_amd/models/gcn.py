@@ -346,8 +346,7 @@ class StagePipeline:
         """All-gather in column chunks: the feature columns are cut into `chunks` slabs (at multiples of 32
         floats) and the all-gather of slab c + 1 travels while slab c is multiplied -- the collective keeps
         every xGMI link busy AND overlaps the SpMM. Columns are independent, so the bits do not change."""
-        env = DistEnv.env
-        rank, timer = env.rank, env.timer
+        timer = DistEnv.env.timer
         P, s, F = len(stages), feat.size(0), feat.size(1)
         step = (-(-F // chunks) + 31) // 32 * 32                  # columns per slab: ceil(F / chunks), on a 32-float grid
         bounds = [(c0, min(c0 + step, F)) for c0 in range(0, F, step)]

@@ -562,7 +562,6 @@ def _plan_for_sparse(A, F):
 def bundle_stage_count(n, m, nnz, F):
     """Column-block stages of a bundle plan: a bundle's run is the union of four rows' runs, so runs stay long with more
     stages than default_stage_count allows (measured on the Reddit shape: 6 instead of 4 at 602 floats)."""
-    ld = padded_width(F)
     if n == 0 or nnz == 0:
         return 1
     by_cache = -(-m * 256 // (10 << 20))

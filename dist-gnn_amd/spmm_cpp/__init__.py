@@ -956,7 +956,9 @@ def _dense_for(A):
     # blocks under ~8 M nonzeros (the blocks of a 4- or 8-rank partition) are too small for it: a few hundred pieces do
     # not fill the chip (measured on an 8-way Reddit-shaped partition: 8 block products 1.8 -> 2.8 ms, while the rank's
     # 14 M-nonzero row slab gains 10 %)
-    if want == '0' or A.nnz < (1 << 23) or float(A.nnz) / max(A.n, 1) < 32:
+    min_nnz = int(os.environ.get('DGNN_DENSE_MIN_NNZ', 1 << 23))       # (tests lower both floors to run small models on tiles)
+    min_deg = float(os.environ.get('DGNN_DENSE_MIN_DEG', 32))
+    if want == '0' or A.nnz < max(min_nnz, 1) or float(A.nnz) / max(A.n, 1) < min_deg:
         return None
     if '_dense_plan' not in A.__dict__:
         D = DensePlan(A)

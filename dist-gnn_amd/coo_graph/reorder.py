@@ -10,7 +10,8 @@ holds the edge list:
   'bfs'      breadth-first numbering from the highest-degree node (Cuthill-McKee without the degree tie-break): a
              node's neighbours get nearby ids, so a 1D row block references fewer distinct rows of the other blocks
              (needed-rows transfer) and a lane group's gathers stay closer together (L2);
-  'degree'   descending degree (hub rows and hub columns first).
+  'degree'   descending degree (hub rows and hub columns first);
+  'cluster'  label-propagation clusters, members numbered consecutively (the closest stand-in for METIS parts).
 
 A reordered dataset is a DIFFERENT input with the same answer up to the permutation: results are permuted, not
 changed (tests/test_reorder.py). ``prepare_data.py --reorder bfs`` writes it as dataset ``<name>_reorder``, the tag
@@ -80,7 +81,35 @@ def bfs_order(edge_index, n, max_levels=10000):
     return order
 
 
-ORDERS = {'bfs': bfs_order, 'degree': degree_order}
+def cluster_order(edge_index, n, rounds=8):
+    """Clustering order by label propagation (what METIS's parts were for the reference, without METIS): every node
+    starts as its own label; in each round a node takes the label most frequent among its neighbours and itself (ties:
+    the smallest label), synchronously; after `rounds` rounds nodes are sorted by (label, old id), so the members of a
+    cluster get consecutive ids. Unlike the breadth-first numbering it is not thrown off by the few long-range edges
+    of a small-world graph. Deterministic; torch ops on the edge list's device (one sort over the edges per round)."""
+    ei = edge_index.long()
+    dev = ei.device
+    loops = torch.arange(n, device=dev)
+    src = torch.cat([ei[0], ei[1], loops])                           # undirected, with self loops
+    dst = torch.cat([ei[1], ei[0], loops])
+    label = torch.arange(n, device=dev)
+    for _ in range(rounds):
+        key, cnt = torch.unique(dst * n + label[src], return_counts=True)      # (node, label) pairs, ascending
+        node = key // n
+        # per node the pair with the largest count, first (= smallest label) among equals: sort by (node, -count) stably
+        order = torch.argsort(node * (cnt.max() + 1) + (cnt.max() - cnt), stable=True)
+        node_s = node[order]
+        first = torch.ones_like(node_s, dtype=torch.bool)
+        first[1:] = node_s[1:] != node_s[:-1]
+        new = label.clone()
+        new[node_s[first]] = (key[order] % n)[first]
+        if torch.equal(new, label):
+            break
+        label = new
+    return torch.argsort(label * n + torch.arange(n, device=dev))
+
+
+ORDERS = {'bfs': bfs_order, 'degree': degree_order, 'cluster': cluster_order}
 
 
 def reorder_dataset(d, how):

@@ -62,6 +62,29 @@ def rmat_undirected(num_nodes, num_edges, seed=0, device='cpu', abcd=(0.57, 0.19
     return keys
 
 
+def planted_undirected(num_nodes, num_edges, community=2048, p_in=0.9, seed=0, device='cpu'):
+    """Distinct undirected edges of a graph WITH locality (for the reordering experiments; R-MAT has none): nodes live
+    in communities of `community` consecutive hidden ids, an edge stays inside its first endpoint's community with
+    probability p_in and goes anywhere otherwise; the visible ids are a seeded scramble of the hidden ones, as for
+    R-MAT. Same key format as rmat_undirected (u * N + v, u < v); at least num_edges * 0.98 edges (one draw, de-duplicated)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    perm = torch.randperm(num_nodes, generator=gen, device=dev)
+    todo = int(num_edges * 1.02) + 1024
+    u = torch.randint(0, num_nodes, (todo,), generator=gen, device=dev)
+    inside = torch.rand(todo, generator=gen, device=dev) < p_in
+    base = u // community * community
+    width = torch.clamp(torch.full_like(u, community), max=num_nodes) - torch.clamp(base + community - num_nodes, min=0)
+    v_in = base + (torch.rand(todo, generator=gen, device=dev) * width).long().clamp(max=community - 1)
+    v_out = torch.randint(0, num_nodes, (todo,), generator=gen, device=dev)
+    v = torch.where(inside, v_in, v_out).clamp(max=num_nodes - 1)
+    ok = u != v
+    a, b = perm[u[ok]], perm[v[ok]]
+    keys = torch.unique(torch.minimum(a, b) * num_nodes + torch.maximum(a, b))
+    return keys[:num_edges] if keys.numel() > num_edges else keys
+
+
 def make_dataset(shape='cora', seed=0, device='cpu', num_nodes=None, num_edges=None, num_features=None,
                  num_classes=None, train_fraction=None, with_features=True):
     """A dataset dict in the reference's schema with the counts of `shape` (overridable)."""

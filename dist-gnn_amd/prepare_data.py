@@ -12,7 +12,7 @@ def main(argv=None):
     ap.add_argument('--no-cache', action='store_true')
     ap.add_argument('--no-csr', action='store_true', help='do not store the int32 CSR blocks in the part files')
     ap.add_argument('--transpose', action='store_true', help='also store the blocks of A^T (exact backward on directed graphs)')
-    ap.add_argument('--reorder', default=None, choices=['bfs', 'degree'],
+    ap.add_argument('--reorder', default=None, choices=['bfs', 'degree', 'cluster'],
                     help='relabel the nodes for locality first (1D_CAGNET/partition_torch_ready_data.py:15-57 did this with '
                          'METIS); the result is written as dataset <name>_reorder')
     args = ap.parse_args(argv)

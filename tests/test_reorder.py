@@ -18,7 +18,7 @@ def _graph(seed=4, n=157, e=900, f=9):
             "num_nodes": n, "num_edges": e, "num_classes": 5}
 
 
-@pytest.mark.parametrize('how', ['bfs', 'degree'])
+@pytest.mark.parametrize('how', ['bfs', 'degree', 'cluster'])
 def test_reordering_is_a_pure_relabelling(how):
     from coo_graph import reorder, graph_utils, parted_coo_graph
     from oracle import ref_cpu
@@ -68,3 +68,25 @@ def test_bfs_order_puts_neighbours_close():
     assert int((new['edge_index'][0] - new['edge_index'][1]).abs().max()) <= 2
     with pytest.raises(ValueError):
         reorder.relabel(raw, torch.zeros(n, dtype=torch.long))
+
+
+def test_cluster_order_recovers_planted_communities():
+    """Label-propagation clustering on a graph with communities behind scrambled ids (synthetic.planted_undirected):
+    after the relabelling most edges join nodes whose ids are less than a community apart; the breadth-first numbering,
+    thrown off by the 10 % long-range edges, does not get there."""
+    from coo_graph import reorder, synthetic
+    n, c = 12000, 400
+    keys = synthetic.planted_undirected(n, 120000, community=c, seed=2)
+    lo, hi = keys // n, keys % n
+    assert keys.numel() >= 0.95 * 120000 and bool((lo < hi).all())
+    ei = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
+
+    def near(order):
+        new = torch.empty(n, dtype=torch.long)
+        new[order] = torch.arange(n)
+        return float(((new[ei[0]] - new[ei[1]]).abs() < c).float().mean())
+    assert near(torch.arange(n)) < 0.2                                   # scrambled ids: no locality to begin with
+    got = near(reorder.cluster_order(ei, n))
+    assert got > 0.8, got
+    assert near(reorder.bfs_order(ei, n)) < got
+    assert torch.equal(reorder.cluster_order(ei, n), reorder.cluster_order(ei, n))      # deterministic

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--rest', default='auto', help='plan of the remainder: auto | bundle | runs')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--rest-variants', default='', help='library variants to time the remainder plan with (102..108: gathers in flight)')
+    ap.add_argument('--rest-R', type=int, default=4, help='rows per bundle of a bundle plan of the remainder')
     ap.add_argument('--rest-stages', default='0', help='column-block stages of the remainder plan (0 = the rule)')
     ap.add_argument('--variants', default='', help='library debug variants to time the tile kernel with (results are wrong)')
     args = ap.parse_args()
@@ -64,7 +65,7 @@ def main():
                         if args.rest == 'auto' and not rs:
                             rp = spmm_cpp._plan_for_sparse(D.rest, F)
                         elif args.rest == 'bundle':
-                            rp = spmm_cpp.BundlePlan(D.rest, rs or spmm_cpp.bundle_stage_count(A.n, A.m, D.rest.nnz, F), 4)
+                            rp = spmm_cpp.BundlePlan(D.rest, rs or spmm_cpp.bundle_stage_count(A.n, A.m, D.rest.nnz, F), args.rest_R)
                         else:
                             rp = spmm_cpp.SegPlan(D.rest, rs or spmm_cpp.default_stage_count(A.n, A.m, D.rest.nnz, F))
                         hp = spmm_cpp.HybridPlan(D, rp)

@@ -16,11 +16,16 @@ import spmm_cpp  # noqa: E402
 from coo_graph import synthetic, graph_utils  # noqa: E402
 
 
-def build_graph(shape, scale, seed, dev, reorder=None):
+def build_graph(shape, scale, seed, dev, reorder=None, planted=0):
     n, e, f, c, _ = synthetic.SHAPES[shape]
     n, e = int(n * scale), int(e * scale * scale) if scale < 1 else e
     t0 = time.time()
-    d = synthetic.make_dataset(shape, seed=seed, device=dev, num_nodes=n, num_edges=e, with_features=False)
+    if planted:                      # the shape's node / edge counts on a graph with communities of `planted` nodes
+        keys = synthetic.planted_undirected(n, e, community=planted, seed=seed, device=dev)
+        lo, hi = keys // n, keys % n
+        d = dict(edge_index=torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])]))
+    else:
+        d = synthetic.make_dataset(shape, seed=seed, device=dev, num_nodes=n, num_edges=e, with_features=False)
     ei = d['edge_index']
     if reorder:                      # what `prepare_data.py --reorder ...` gives: the same graph, nodes relabelled
         from coo_graph import reorder as _reorder
@@ -66,10 +71,11 @@ def main():
     ap.add_argument('--builder', default='torch', choices=['torch', 'device'], help='who builds the work plans')
     ap.add_argument('--drop-in', action='store_true', help='also time the reference-signature call spmm_cusparse(row, col, val, ...)')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
-    ap.add_argument('--reorder', default=None, choices=['degree', 'bfs'], help='relabel the nodes first (coo_graph/reorder.py)')
+    ap.add_argument('--planted', type=int, default=0, help='instead of R-MAT: communities of this many nodes (a graph with locality, ids scrambled)')
+    ap.add_argument('--reorder', default=None, choices=['degree', 'bfs', 'cluster'], help='relabel the nodes first (coo_graph/reorder.py)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
-    A, adj = build_graph(args.shape, args.scale, 0, dev, args.reorder)
+    A, adj = build_graph(args.shape, args.scale, 0, dev, args.reorder, args.planted)
     deg = (A.rowptr[1:] - A.rowptr[:-1]).float()
     print(f'# degree: mean {deg.mean().item():.1f} max {int(deg.max().item())} p99 {deg.quantile(0.99).item():.0f}', flush=True)
     sd, _ = torch.sort(deg, descending=True)

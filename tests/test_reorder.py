@@ -90,3 +90,31 @@ def test_cluster_order_recovers_planted_communities():
     assert got > 0.8, got
     assert near(reorder.bfs_order(ei, n)) < got
     assert torch.equal(reorder.cluster_order(ei, n), reorder.cluster_order(ei, n))      # deterministic
+
+
+def _cpu_block(ei, n):
+    import spmm_cpp
+    from coo_graph import graph_utils
+    adj = graph_utils.sym_normalization(ei, n).coalesce()
+    idx, val = adj.indices(), adj.values()
+    rp = torch.zeros(n + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(torch.bincount(idx[0], minlength=n), 0).int()
+    return spmm_cpp.CsrBlock(n, n, rp, idx[1].int(), val)
+
+
+def test_locality_share_tells_a_clustered_graph_from_a_scrambled_one():
+    """spmm_cpp.locality_share (what decides the row-bucketed work order): high after the cluster order on a graph with
+    communities, low on the same graph with scrambled ids and on R-MAT."""
+    import spmm_cpp
+    from coo_graph import reorder, synthetic
+    n = 40000
+    keys = synthetic.planted_undirected(n, 400000, community=2048, seed=1)
+    lo, hi = keys // n, keys % n
+    ei = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
+    assert spmm_cpp.locality_share(_cpu_block(ei, n)) < 0.3
+    order = reorder.cluster_order(ei, n)
+    new = torch.empty(n, dtype=torch.long)
+    new[order] = torch.arange(n)
+    assert spmm_cpp.locality_share(_cpu_block(new[ei], n)) > 0.6
+    d = synthetic.make_dataset('reddit', seed=0, device='cpu', num_nodes=n, num_edges=1500000, with_features=False)
+    assert spmm_cpp.locality_share(_cpu_block(d['edge_index'], n)) < 0.3

@@ -847,3 +847,41 @@ def test_dense_entry_point_rejects_bad_arguments():
         spmm_cpp.spmm_dense(D, B, C)
     with pytest.raises(ValueError):
         spmm_cpp.DensePlan(blk, 3, 8, 100)                                   # piece length must be a multiple of 8
+
+
+def test_row_bucketed_order_is_chosen_for_blocks_with_locality_and_changes_no_bit():
+    """A graph with communities, relabelled by the cluster order (prepare_data.py --reorder cluster): the plan rule
+    sees the locality (spmm_cpp.locality_share) and lists the runs longest-first inside buckets of 4096 consecutive
+    rows, in one stage. Only the ORDER of the work changes: the result keeps the strict chain's bits on every uncut
+    row, as with the global order; a scrambled graph keeps the global order."""
+    import spmm_cpp
+    from coo_graph import graph_utils, reorder, synthetic
+    dev = torch.device('cuda:0')
+    n = 70000
+    keys = synthetic.planted_undirected(n, 700000, community=2048, seed=4, device=dev)
+    lo, hi = keys // n, keys % n
+    ei = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
+    order = reorder.cluster_order(ei, n)
+    new = torch.empty(n, dtype=torch.long, device=dev)
+    new[order] = torch.arange(n, device=dev)
+    B = torch.rand(n, 200, device=dev)
+    for edges, local in ((new[ei], True), (ei, False)):
+        A = spmm_cpp.CsrBlock.from_coo(graph_utils.sym_normalization(edges, n))
+        assert A.nnz >= 1 << 20
+        plan = spmm_cpp._plan_for(A, 200)
+        assert isinstance(plan, spmm_cpp.SegPlan)
+        assert (plan.row_bucket == spmm_cpp.ROW_BUCKET and plan.nstage == 1) if local else plan.row_bucket == 0
+        if local:                                              # inside a bucket: longest first; buckets in row order
+            seg = plan.seg.long()
+            bk = seg[:, 0] // spmm_cpp.ROW_BUCKET
+            assert bool((bk[1:] >= bk[:-1]).all())
+            ln = seg[:, 2] - seg[:, 1]
+            same = bk[1:] == bk[:-1]
+            assert bool((ln[1:][same] <= ln[:-1][same]).all())
+        Z = torch.full((n, 200), float('nan'), device=dev)
+        spmm_cpp.aggregate(A, B, Z, overwrite=True)
+        Zk = torch.zeros(n, 200, device=dev)
+        spmm_cpp.spmm_csr(A, B, Zk, 1.0, 0.0)
+        uncut = plan.uncut_rows()
+        assert int(uncut.sum()) > 0.99 * n and torch.equal(Z[uncut], Zk[uncut])
+        assert ((Z - Zk).abs() <= 1e-5 * Zk.abs()).all()

@@ -71,6 +71,7 @@ def main():
     ap.add_argument('--builder', default='torch', choices=['torch', 'device'], help='who builds the work plans')
     ap.add_argument('--drop-in', action='store_true', help='also time the reference-signature call spmm_cusparse(row, col, val, ...)')
     ap.add_argument('--plans', default='', help='auto or nstage:piece_len;...')
+    ap.add_argument('--row-bucket', type=int, default=0, help='SegPlan(row_bucket=...): runs longest-first inside buckets of this many consecutive rows')
     ap.add_argument('--planted', type=int, default=0, help='instead of R-MAT: communities of this many nodes (a graph with locality, ids scrambled)')
     ap.add_argument('--reorder', default=None, choices=['degree', 'bfs', 'cluster'], help='relabel the nodes first (coo_graph/reorder.py)')
     args = ap.parse_args()
@@ -137,7 +138,7 @@ def main():
             if (ns, pl_len, nhot) not in plans:
                 t0 = time.perf_counter()
                 plans[(ns, pl_len, nhot)] = (spmm_cpp.DevicePlan(A, ns, pl_len, F) if args.builder == 'device'
-                                             else spmm_cpp.SegPlan(A, ns, pl_len))
+                                             else spmm_cpp.SegPlan(A, ns, pl_len, row_bucket=args.row_bucket))
                 torch.cuda.synchronize()
                 print(f'# {args.builder} plan built in {1e3 * (time.perf_counter() - t0):.1f} ms', flush=True)
                 pp = plans[(ns, pl_len, nhot)]

@@ -51,3 +51,14 @@ def test_broadcast_micro_benchmark_runs_on_gloo(tmp_path):
             for f in fs:
                 log += open(os.path.join(root, f)).read()
     assert 'all_gather' in log and '4096 B' in log, log[-1500:]
+
+
+def test_prepare_data_with_the_cluster_reordering(tmp_path):
+    """prepare_data.py --reorder cluster (the stand-in for the reference's METIS step, partition_torch_ready_data.py:15-57)
+    writes the relabelled dataset under <name>_reorder with the same node, edge and part counts."""
+    tmp = str(tmp_path)
+    r = _run(['prepare_data.py', '--dataset', 'cora', '--parts', '2', '--reorder', 'cluster'], tmp)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = sorted(os.listdir(os.path.join(tmp, 'data')))
+    assert 'cora_reorder_GCN_2_parts' in files, files
+    assert '<COO Graph: cora_reorder' in r.stdout and '|V|: 1354' in r.stdout

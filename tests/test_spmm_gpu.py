@@ -268,17 +268,30 @@ def test_older_extension_name_and_signatures():
     assert sparse_coo_tensor_gpu(idx[:, :1], torch.tensor(2.0, device=dev), (n, m))._values().shape == (1,)
 
 
-def test_plan_spmm_can_be_captured_in_a_hip_graph():
-    """The fast-path entry point only launches kernels on the given stream (no allocation, no synchronisation),
-    so a caller may capture it in a HIP graph and replay it on new operand contents."""
+@pytest.mark.parametrize('kind', ['runs', 'bundles', 'tiles'])
+def test_plan_spmm_can_be_captured_in_a_hip_graph(kind):
+    """The fast-path entry points only launch kernels on the given stream (no allocation, no synchronisation),
+    so a caller may capture them in a HIP graph and replay it on new operand contents: run plans, bundle plans, and
+    dense tiles + remainder (two entry points back to back)."""
     import spmm_cpp
     rng = np.random.default_rng(77)
     n, m, F = 3000, 2500, 256
     row, col, val = _rand_csr(rng, n, m, 90000, hub_rows=3)
+    fold = rng.random(col.size) < 0.5                    # popular columns: something for bundles and tiles to share
+    key = np.unique(row.astype(np.int64) * m + np.where(fold, col % 120, col))
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    val = rng.random(key.size, dtype=np.float32)
     dev = torch.device('cuda:0')
     blk = _gpu_block(row, col, val, n, m)
-    plan = spmm_cpp.SegPlan(blk, 3, 64)                 # three stages, cut rows: stage kernels + merge kernels
-    assert plan.ncut > 0
+    if kind == 'runs':
+        plan = spmm_cpp.SegPlan(blk, 3, 64)             # three stages, cut rows: stage kernels + merge kernels
+    elif kind == 'bundles':
+        plan = spmm_cpp.BundlePlan(blk, 3, 4, 64)
+    else:
+        D = spmm_cpp.DensePlan(blk, 3, 8, 64)
+        assert D.nk > 0 and D.ncut > 0
+        plan = spmm_cpp.HybridPlan(D, spmm_cpp.SegPlan(D.rest, 2, 64))
+    assert (plan.rest_plan if kind == 'tiles' else plan).ncut > 0
     B = spmm_cpp.pad_rows(torch.rand(m, F, device=dev))
     C = torch.zeros(n, F, device=dev)
     spmm_cpp.spmm_plan(blk, B, C, 1.0, 0.0, plan)       # warm-up: sizes the partial buffer outside the capture

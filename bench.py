@@ -338,6 +338,10 @@ def main():
         moved, full = pipe.rows_moved - rows0[0], pipe.rows_full - rows0[1]
         comm = dict(form=pipe.describe(), recv_bytes_per_rank_per_step=int(wire), exposed_ms_per_step=exposed,
                     recv_GBps_if_fully_exposed=round(wire / max(exposed, 1e-6) / 1e6, 1),
+                    # per xGMI link (world - 1 peers, one link each on a fully connected node) against 153 GB/s;
+                    # a lower bound on the link rate, since only the exposed wait is in the denominator
+                    per_link_GBps_if_fully_exposed=round(wire / max(exposed, 1e-6) / 1e6 / max(world - 1, 1), 1),
+                    exposed_share_of_step=round(exposed / max(elapsed / args.steps * 1e3, 1e-9), 3),
                     xgmi_link_peak_GBps=153.0, needed_rows_fraction=(round(moved / full, 4) if full else None))
     # Beside the headline (never part of it): the same epochs with the opt-in A_hat (H W) ordering, in which a
     # layer with F_out < F_in aggregates at the narrower width (re-associated fp32, <= 1e-5).

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from coo_graph import Parted_COO_Graph
+from dist_utils import tune_gemms
 from models import GCN, CachedGCN
 
 
@@ -74,6 +75,8 @@ def train_step(model, optimizer, loss_func, g, env):
 
 
 def train(g, env, total_epoch, model='GCN', hidden_dim=256, num_layers=3, lr=0.01, eval_every=10):
+    if env.device.type == 'cuda':
+        tune_gemms()                 # the X W products: fastest library kernel per shape, found in the first epoch
     net = build_model(g, env, model, hidden_dim, num_layers)
     optimizer = torch.optim.Adam(net.parameters(), lr=lr)
     loss_func = nn.CrossEntropyLoss() if g.labels.dim() == 1 else nn.BCEWithLogitsLoss(reduction='mean')

@@ -5,5 +5,6 @@ Keeps the reference's names (light_dist_gnn/dist_utils/__init__.py: ``from .env 
 from .env import DistEnv
 from .timer import DistTimer
 from .logger import DistLogger
+from .gemm import tune_gemms
 
-__all__ = ['DistEnv', 'DistTimer', 'DistLogger']
+__all__ = ['DistEnv', 'DistTimer', 'DistLogger', 'tune_gemms']

@@ -21,3 +21,8 @@ def golden_dir():
 # aggregation outputs are allocated uninitialised on the HIP path (the first stage product overwrites them):
 # under test they are filled with NaN first, so an element nobody stores cannot pass for a zero
 os.environ.setdefault('DGNN_POISON', '1')
+
+# dist_train.train() lets PyTorch time every library GEMM candidate per shape (dist_utils/gemm.py); with dozens of small
+# shapes and up to 8 test ranks on one GPU that is minutes of timing runs that check nothing. The suite runs on the
+# library's default kernels; test_train_gpu.py turns the tuner on in a child process for the golden loss curve.
+os.environ.setdefault('DGNN_TUNE_GEMM', '0')

@@ -87,6 +87,11 @@ def test_layer_and_training_curve_on_gpu(env, golden_dir, name):
     losses = dist_train.train(pg, env, total_epoch=5)
     np.testing.assert_allclose(np.array(losses), w['r0_losses'], rtol=1e-4, atol=1e-4)           # curves overlay
     assert 'spmm' in env.timer.summary() and env.timer.count_dict['spmm'] > 0
+    import torch.cuda.tunable as tunable
+    if os.environ.get('DGNN_TUNE_GEMM') == '1':      # the child of test_golden_loss_curve_with_tuned_library_gemms
+        assert tunable.is_enabled() and len(tunable.get_results()) > 0
+    else:
+        assert not tunable.is_enabled()
 
 
 def test_cpu_tensors_fail_loudly_in_the_model_path(env):
@@ -223,3 +228,25 @@ def test_golden_layer_and_loss_curve_with_tiles_forced_on_small_blocks():
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+def test_golden_loss_curve_with_tuned_library_gemms():
+    """dist_train.train() turns PyTorch's TunableOp on (dist_utils.tune_gemms: the fastest rocBLAS / hipBLASLt kernel per
+    X W shape). fp32 stays fp32, so the reference's loss curve must still hold at its tolerance whichever kernels win;
+    run in a child process because the tuner's switch is process-wide. The child must leave no results file behind."""
+    import glob
+    import subprocess
+    import sys
+    import tempfile
+    env = dict(os.environ, DGNN_TUNE_GEMM='1')
+    env.pop('PYTORCH_TUNABLEOP_FILENAME', None)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    before = set(glob.glob(os.path.join(ROOT, '*.csv')) + glob.glob(os.path.join(tempfile.gettempdir(), 'dgnn_tunableop_*')))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider',
+                        os.path.join(ROOT, 'tests', 'test_train_gpu.py'), '-k', 'layer_and_training_curve'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
+    after = set(glob.glob(os.path.join(ROOT, '*.csv')) + glob.glob(os.path.join(tempfile.gettempdir(), 'dgnn_tunableop_*')))
+    assert after == before, after - before

@@ -2,7 +2,8 @@
 # Round profiling recipe (run on the GPU box from the repo root):
 #   bash tools/profile_round.sh r01
 # 1. default bench line; 2. rocprofv3 kernel trace + stats of the same command (no CPU leg);
-# 3./4. separate PMC passes for HBM-side read / write bytes. Raw CSVs stay in /tmp; only summaries
+# 3./4. separate PMC passes for HBM-side read / write bytes (GEMM tuner off there: its thousands of timing launches
+# would each be serialised by the counters, and the SpMM kernels these passes read do not depend on it). Raw CSVs stay in /tmp; only summaries
 # land in gpurun_out/prof_<tag>/ (copy the ones to keep into profiles/).
 set -o pipefail
 tag=${1:-r01}
@@ -22,12 +23,12 @@ python tools/pmc_summary.py "$raw/kt" spmm_ > "$out/kernel_durations.txt"
 python tools/pmc_summary.py "$raw/kt" merge_ >> "$out/kernel_durations.txt"
 echo "kernel trace done"
 
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$raw/fetch" -- \
+DGNN_TUNE_GEMM=0 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$raw/fetch" -- \
     python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err" || exit 4
 python tools/pmc_summary.py "$raw/fetch" "_kernel<" | grep -A1 -E "spmm_(stage|bundle|hot|dense)_kernel" | grep -v "^--" > "$out/pmc_fetch_size.txt"
 echo "fetch pass done"
 
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$raw/write" -- \
+DGNN_TUNE_GEMM=0 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$raw/write" -- \
     python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_write_bench.json" 2> "$out/pmc_write.err" || exit 5
 python tools/pmc_summary.py "$raw/write" "_kernel<" | grep -A1 -E "spmm_(stage|bundle|hot|dense)_kernel" | grep -v "^--" > "$out/pmc_write_size.txt"
 echo "write pass done"

@@ -44,9 +44,9 @@ per = {k: dict(launches=f[k][0], fetch_bytes_per_launch=int(f[k][1] * 2048 / f[k
                write_bytes_per_launch=int(w[k][1] * 1024 / w[k][0])) for k in f}
 d = dict(hbm_bytes_per_launch=int((fetch + write) / n), launches_in_pass=n, fetch_bytes_per_launch=int(fetch / n),
          write_bytes_per_launch=int(write / n), per_kernel=per, commit=(sys.argv[3] if len(sys.argv) > 3 else 'unknown'),
-         command='python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2',
-         how="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-budget 0 "
-             "--steps 3 --warmup 2` (KiB per dispatch; FETCH_SIZE doubled for gfx950 per MI355X_MICROARCH.md), averaged "
+         command='DGNN_TUNE_GEMM=0 python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2',
+         how="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `DGNN_TUNE_GEMM=0 python bench.py --cpu-budget 0 "
+             "--steps 3 --warmup 2` (library-default GEMMs there; the SpMM launches are the same) (KiB per dispatch; FETCH_SIZE doubled for gfx950 per MI355X_MICROARCH.md), averaged "
              "over all SpMM stage launches of the pass (spmm_dense_kernel, spmm_bundle_kernel and spmm_stage_kernel); counts L2-side fabric requests, Infinity-Cache hits included")
 json.dump(d, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
 print(json.dumps(d, indent=1))

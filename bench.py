@@ -243,9 +243,10 @@ def main():
         os.environ['DGNN_GLOO_CUDA'] = '1'
     env = dist_utils.DistEnv(rank, world, args.backend, echo=False)
     dev = env.device
-    tuned = dist_utils.tune_gemms()          # as dist_train.train does: the picks are made in the warm-up epochs
+    # as dist_train.train does: the picks are made in the warm-up epochs (not in the gloo rehearsal, where the ranks share a GPU)
+    tuned = dist_utils.tune_gemms(None if args.backend == 'nccl' else False)
 
-    t_build = time.time()
+    t_build = t_start = time.time()
     g, n_nodes, nnz_total = build_rank_graph(args, env)
     model = dist_train.build_model(g, env, args.model, args.hidden, layers, rep=args.rep)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
@@ -260,8 +261,14 @@ def main():
         epoch_no[0] += 1
         return dist_train.train_step(model, optimizer, loss_func, g, env)
 
-    for _ in range(args.warmup):          # also builds the CSR blocks and work plans (once)
+    def say(msg):                          # progress on stderr (stdout carries the one JSON line): a products-shape run is
+        if rank == 0:                      # minutes of set-up, plans and GEMM tuning before the first timed epoch
+            print(f'[bench +{time.time() - t_start:.0f}s] {msg}', file=sys.stderr, flush=True)
+    say(f'graph and model built ({t_build:.1f} s)')
+    for i in range(args.warmup):          # also builds the CSR blocks and work plans (once)
         step()
+        torch.cuda.synchronize()
+        say(f'warm-up epoch {i + 1} of {args.warmup} done')
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -278,6 +285,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = spmm_cpp.prof_end()
+    say(f'{args.steps} timed epochs done')
     env.timer.resolve()
     # GPU time per step under the reference's timer keys (HIP events on the compute stream; 'broadcast' is
     # the time the compute stream sat waiting for a feature block = exposed communication)

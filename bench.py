@@ -250,7 +250,7 @@ def main():
     g, n_nodes, nnz_total = build_rank_graph(args, env)
     model = dist_train.build_model(g, env, args.model, args.hidden, layers, rep=args.rep)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
-    loss_func = torch.nn.NLLLoss() if args.model == 'AdaptiveGCN' else torch.nn.CrossEntropyLoss()
+    loss_func = torch.nn.NLLLoss() if args.model == 'AdaptiveGCN' else dist_train.cross_entropy_mean   # as dist_train.train
     epoch_no = [0]
     torch.cuda.synchronize()
     t_build = time.time() - t_build

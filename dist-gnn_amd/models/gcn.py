@@ -203,6 +203,11 @@ class _Sum:
         return self.z
 
 
+def _row_padded(t):
+    import spmm_cpp
+    return spmm_cpp.is_row_padded(t)
+
+
 def _new_output(rows, feat, padded):
     """The [rows, F] output of an aggregation. On the HIP path it is NOT zero-filled: the first stage product
     overwrites it (_Sum). ``padded``: a [rows, F] view of a buffer at the kernel's 128-byte row pitch (aligned
@@ -295,11 +300,16 @@ class StagePipeline:
         return ld if (ld - F) * 16 <= F else F
 
     def _own_block(self, feat, ld):
-        """This rank's block as it travels: feat itself, or a padded copy [s, ld]."""
-        if ld == feat.size(1):
-            return feat
-        import spmm_cpp
-        return spmm_cpp.pad_rows(feat, self._buffers((feat.size(0), ld), feat, 1, 'own')[0])
+        """This rank's block as it travels (contiguous [s, ld]): feat itself, its rows with their padding when it is
+        stored at the padded pitch already (spmm_cpp.row_padded: the input features), or a padded copy."""
+        s, F = feat.shape
+        if ld == F:
+            return feat.contiguous()
+        if (feat.stride(1) == 1 and feat.stride(0) == ld and feat.data_ptr() % 128 == 0
+                and (feat.storage_offset() + s * ld) * feat.element_size() <= feat.untyped_storage().nbytes()):
+            return feat.as_strided((s, ld), (ld, 1))      # the columns past F travel too; they only ever meet the
+        import spmm_cpp                                    # padding columns of a product
+        return spmm_cpp.pad_rows(feat, self._buffers((s, ld), feat, 1, 'own')[0])
 
     def describe(self):
         """What 'auto' settled on, for logs and the bench line."""
@@ -688,7 +698,8 @@ class StagePipeline:
         if stages is None:
             stages = [(j, j) for j in range(env.world_size)]
         given = feat
-        orig = feat.contiguous()
+        # a matrix stored at the kernels' row pitch (the input features, spmm_cpp.row_padded) is read as it lies
+        orig = feat if (feat.is_cuda and _spmm_override is None and _row_padded(feat)) else feat.contiguous()
         # Collectives run on a view with its own version counter: a rooted broadcast "writes" its buffer on
         # the root too as far as autograd can tell (gloo's CUDA path really does), and this tensor is often
         # saved for backward (a ReLU output). Its bits are never changed here.
@@ -881,6 +892,11 @@ class GCN(nn.Module):
         torch.manual_seed(0)
         for i in range(num_layers):
             setattr(self, f'weight{i + 1}', nn.Parameter(torch.rand(dims[i], dims[i + 1]).to(env.device)))
+        if g.features.is_cuda and g.features.dtype == torch.float32 and _spmm_override is None:
+            # the input features are aggregated every epoch and never change: store them at the kernels' row pitch
+            # once (same values, a [n, F] view of a zero-padded buffer) instead of copying them there per epoch
+            import spmm_cpp
+            g.features = spmm_cpp.row_padded(g.features)
 
     def forward(self, features):
         h = features

@@ -283,6 +283,29 @@ def pad_rows(src, dst=None):
     return dst
 
 
+def is_row_padded(t):
+    """True when the kernels can read ``t`` ([n, F] fp32 on the GPU) in place as a B operand: unit column stride,
+    rows at the padded pitch, first row on a 128-byte line. (A contiguous matrix whose width is a multiple of 32
+    floats qualifies as it is.)"""
+    return (t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1
+            and t.stride(0) == padded_width(t.size(1)) and t.data_ptr() % 128 == 0)
+
+
+def row_padded(t):
+    """``t`` stored at the kernels' row pitch: a [n, F] view of a zero-filled [n, padded_width(F)] buffer holding
+    t's values (t itself when it already qualifies). For matrices that are aggregated again and again unchanged --
+    the dataset's input features -- so that no epoch has to copy them into a padded block first."""
+    if is_row_padded(t):
+        return t
+    if not (t.dim() == 2 and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError('row_padded: expected a 2-D fp32 CUDA tensor')
+    n, F = t.shape
+    buf = torch.zeros(n, padded_width(F), dtype=torch.float32, device=t.device)
+    view = buf[:, :F]
+    view.copy_(t)
+    return view
+
+
 def gather_rows(src, idx, dst=None):
     """dst[r] = src[idx[r]] packed at the padded pitch (zero fill): the rows of a feature block one peer
     needs (1D_CAGNET/dist_1d.py:43 ``t[needed_rows_idx]``). ``idx`` int32 on the device, values in

@@ -122,3 +122,19 @@ def test_dense_plan_splits_a_block_into_tiles_and_remainder_exactly():
                         assert cut[r] == (outs[0] + j, len(pieces), 31)
         assert int(D.touched_rows().sum()) == sum(int((rows[t] >= 0).sum()) for t in per_tile)
         assert D.npartial == 32 * sum(len(p) for p in per_tile.values() if len(p) > 1)
+
+
+def test_mean_cross_entropy_spelled_out_equals_nn_cross_entropy():
+    """dist_train.cross_entropy_mean replaces nn.CrossEntropyLoss() (dist_train.py:33) in the training loop: same
+    loss and gradient, ragged batch sizes and one-row batches included."""
+    import dist_train
+    g = torch.Generator().manual_seed(3)
+    for rows, classes in ((1, 7), (37, 41), (1000, 41), (513, 172)):
+        x = (torch.randn(rows, classes, generator=g) * 5).requires_grad_(True)
+        y = torch.randint(0, classes, (rows,), generator=g)
+        want = torch.nn.CrossEntropyLoss()(x, y)
+        gw, = torch.autograd.grad(want, x)
+        got = dist_train.cross_entropy_mean(x, y)
+        gg, = torch.autograd.grad(got, x)
+        assert abs(got.item() - want.item()) <= 1e-6 * max(1.0, abs(want.item()))
+        assert (gg - gw).abs().max().item() <= 1e-7

@@ -133,6 +133,30 @@ def test_transfer_forms_over_rccl_world1(env, F):
     assert torch.equal(z1, want) and torch.equal(z2, want) and torch.equal(z3, want) and torch.equal(z4, want)
     assert torch.equal(z5, want) and torch.equal(z6, want)
     assert 'gathered' in kept and pipe.transfers == 6
+    # the same matrix stored at the kernels' row pitch (what GCN.__init__ does with the input features): read in
+    # place by the SpMM, sent with its padding when the wire is padded, as a contiguous copy otherwise -- same bits
+    import spmm_cpp
+    Hp = spmm_cpp.row_padded(H)
+    assert Hp.shape == H.shape and torch.equal(Hp, H) and spmm_cpp.is_row_padded(Hp) and spmm_cpp.row_padded(Hp) is Hp
+    assert Hp.stride(0) == spmm_cpp.padded_width(F) and (F % 32 != 0) == (Hp.data_ptr() != H.data_ptr())
+    own = pipe._own_block(Hp, pipe._wire_width(Hp))
+    assert own.is_contiguous() and torch.equal(own[:, :F], H)
+    assert (own.data_ptr() == Hp.data_ptr()) == (pipe._wire_width(Hp) == Hp.stride(0))      # in place iff the wire is padded
+    for run in (lambda: pipe._run_bcast([A], Hp, stages, env.world_group, torch.zeros(n, F, device=dev), None, None),
+                lambda: pipe._run_allgather(parts, Hp, stages, env.world_group, torch.zeros(n, F, device=dev), None),
+                lambda: pipe._run_agpipe(parts, Hp, stages, env.world_group, torch.zeros(n, F, device=dev)),
+                lambda: pipe.run([A], Hp, 'ForwardL1')):
+        z = run()
+        torch.cuda.synchronize()
+        assert torch.equal(z, want)
+    calls = []
+    real = spmm_cpp.pad_rows
+    spmm_cpp.pad_rows = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        z = pipe.run([A], Hp, 'ForwardL1')
+    finally:
+        spmm_cpp.pad_rows = real
+    assert torch.equal(z, want) and not calls                  # no per-epoch padding copy any more
 
 
 @pytest.mark.parametrize('F', [602, 100, 41])

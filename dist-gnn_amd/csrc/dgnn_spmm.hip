@@ -916,8 +916,9 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
   }
 }
 
-// C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order). One wave per cut run; a lane owns
-// float4 columns of the (16-B aligned, padded) partial rows and keeps 4 piece loads in flight.
+// C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order). One wave per (cut run, 256-float chunk); a lane owns
+// one float4 column of the (16-B aligned, padded) partial rows and keeps 4 piece loads in flight (16 measured slower:
+// the merges are thousands of short runs, bound by their traffic, not by a chain of round trips).
 template <int VWC>
 __global__ __launch_bounds__(256) void merge_kernel(
     const int4* __restrict__ cut, int32_t ncut, const float* __restrict__ P, int64_t ldp,
@@ -928,7 +929,8 @@ __global__ __launch_bounds__(256) void merge_kernel(
   if (c4.z <= 0) return;                        // unused slot (list sized by an upper bound)
   const int lane = threadIdx.x & 63;
   const int64_t pst = (int64_t)(c4.w + 1) * ldp;   // partial rows of consecutive pieces are c4.w + 1 apart (row bundles: R)
-  for (int f = lane * 4; f < F; f += 256) {
+  // blockIdx.y: the 256-float chunk of the row (one chunk per wave: the chunks of a run are independent chains of loads)
+  for (int f = blockIdx.y * 256 + lane * 4; f < min(F, (int)(blockIdx.y + 1) * 256); f += 256) {
     float* c = C + (int64_t)c4.x * ldc + f;
     f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
     if (!fresh) c_load<VWC>(c, f, F, a01, a23);            // fresh: the row has no value yet (see the stage kernel)
@@ -947,6 +949,14 @@ __global__ __launch_bounds__(256) void merge_kernel(
     }
     c_store<VWC>(c, f, F, a01, a23);
   }
+}
+
+static void launch_merge(int vwc, const int4* cutp, int32_t nc, const float* partial, int64_t ldp, float* C, int64_t ldc,
+                         int32_t F, int fresh, hipStream_t s) {
+  const dim3 grid((unsigned)((nc + 3) / 4), (unsigned)((F > 0 ? F + 255 : 256) / 256));
+  if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh);
+  else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh);
+  else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1640,11 +1650,8 @@ int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
     if (p1 > p0) {
       ProfScope prof(s, 1);
       const int32_t nc = (int32_t)(p1 - p0);
-      const dim3 grid((unsigned)((nc + 3) / 4));
       const int4* cutp = reinterpret_cast<const int4*>(plan->cut) + p0;
-      if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
-      else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
-      else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
+      launch_merge(vwc, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0, s);
       DGNN_HIP(hipGetLastError());
     }
     if (d1 > d0 || p1 > p0) fresh = false;
@@ -1696,11 +1703,8 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
   }
   if (plan->ncut > 0) {
     ProfScope prof(s, 1);
-    const dim3 grid((unsigned)((plan->ncut + 3) / 4));
     const int4* cutp = reinterpret_cast<const int4*>(plan->cut);
-    if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, plan->ncut, partial, ldp, C, ldc, F, 0);
-    else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, plan->ncut, partial, ldp, C, ldc, F, 0);
-    else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, plan->ncut, partial, ldp, C, ldc, F, 0);
+    launch_merge(vwc, cutp, plan->ncut, partial, ldp, C, ldc, F, 0, s);
     DGNN_HIP(hipGetLastError());
   }
   return DGNN_OK;
@@ -1791,10 +1795,7 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
       ProfScope prof(s, 1);
       const int32_t nc = (int32_t)(p1 - p0);
       const int4* cutp = reinterpret_cast<const int4*>(plan->cut) + p0;
-      const dim3 grid((unsigned)((nc + 3) / 4));
-      if (vwc == 4) hipLaunchKernelGGL(merge_kernel<4>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
-      else if (vwc == 2) hipLaunchKernelGGL(merge_kernel<2>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
-      else hipLaunchKernelGGL(merge_kernel<1>, grid, dim3(256), 0, s, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0);
+      launch_merge(vwc, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0, s);
       DGNN_HIP(hipGetLastError());
     }
     if (s1 > s0 || p1 > p0) fresh = false;

@@ -645,6 +645,12 @@ class StagePipeline:
         cap = float(os.environ.get('DGNN_AUTO_CAP_S', 30.0))
         times = {}
         with torch.no_grad():
+            # line the ranks up first: the first epoch is also where each rank times its library GEMM candidates
+            # (dist_utils.tune_gemms), seconds that differ from rank to rank and would otherwise be charged to the
+            # first form tried (and could push it over the cap)
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=vote_dev), group=group)
+            if feat.is_cuda:
+                torch.cuda.synchronize(feat.device)
             alive = []
             for f in forms:                                 # builds CSR blocks, plans and buffers: not timed
                 t = trial(f)

@@ -339,6 +339,13 @@ def main():
                     helper_kernels_ms_per_step=round(prof['other_ms'] / args.steps, 4),
                     spmm_kernel_gedges_per_s=round(len(widths) * local_nnz * args.steps / stage_s / 1e9, 3) if stage_s > 0 else None,
                     gather_tb_per_s=round(sum(4 * F for F in widths) * local_nnz * args.steps / stage_s / 1e12, 3) if stage_s > 0 else None)
+    # the unit these kernels actually load: every nonzero asks the texture-address / L1 path of a CU for one
+    # B-row slice, and that path delivers 64 B per clock per CU -- 256 CUs x 64 B x 2.4 GHz = 39.3 TB/s. Feature bytes
+    # per nonzero over kernel time against that (row bundles and dense tiles serve several nonzeros from one slice, so
+    # this is the rate a one-slice-per-nonzero kernel would need to match them). Informative; `frac` stays the HBM one.
+    if roofline['gather_tb_per_s'] is not None:
+        roofline['l1_path_peak_tb_per_s'] = 39.3
+        roofline['gather_frac_of_l1_path'] = round(roofline['gather_tb_per_s'] / 39.3, 3)
 
     comm = None
     if world > 1:

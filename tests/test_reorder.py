@@ -1,7 +1,6 @@
 """Locality reordering (coo_graph/reorder.py, the mechanism of 1D_CAGNET/partition_torch_ready_data.py:15-57) is a
 pure relabelling: the permuted input gives the permuted answer. Checked with the CPU oracle (no GPU needed)."""
 import os
-import sys
 
 import numpy as np
 import pytest

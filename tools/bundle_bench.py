@@ -2,7 +2,6 @@
 """A/B of the row-bundle kernel (R rows share one gather per union column) against the stage kernel (GPU only).
 python tools/bundle_bench.py --shape reddit --F 602,256 --R 4,8 --stages 4"""
 import argparse
-import ctypes
 import os
 import sys
 import time

@@ -12,7 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'dist-gnn_amd'))
 import spmm_cpp  # noqa: E402
-from coo_graph import synthetic, graph_utils, parted_coo_graph  # noqa: E402
+from coo_graph import synthetic, graph_utils  # noqa: E402
 
 
 def timed(fn, iters=10):

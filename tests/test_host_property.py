@@ -138,3 +138,21 @@ def test_mean_cross_entropy_spelled_out_equals_nn_cross_entropy():
         gg, = torch.autograd.grad(got, x)
         assert abs(got.item() - want.item()) <= 1e-6 * max(1.0, abs(want.item()))
         assert (gg - gw).abs().max().item() <= 1e-7
+
+
+def test_gemm_tuner_and_row_pitch_helpers_without_a_gpu(monkeypatch):
+    """On a CPU-only box the training drivers' GPU-side conveniences stand aside: the GEMM tuner reports off, and a CPU matrix never counts as stored at the kernels' row pitch (the pipeline then takes its
+    contiguous copy, as before)."""
+    import dist_utils
+    import spmm_cpp
+    if torch.cuda.is_available():
+        return                                          # (the GPU suite covers the other side)
+    monkeypatch.setenv('DGNN_TUNE_GEMM', '1')
+    assert dist_utils.tune_gemms() is False and dist_utils.tune_gemms(True) is False     # (and touched no HIP call: there is no device)
+    x = torch.rand(5, 64)
+    assert not spmm_cpp.is_row_padded(x) and spmm_cpp.padded_width(41) == 64 and spmm_cpp.padded_width(602) == 608
+    try:
+        spmm_cpp.row_padded(x)
+        raise AssertionError('row_padded accepted a CPU tensor')
+    except RuntimeError as e:
+        assert 'CUDA' in str(e)

@@ -265,10 +265,18 @@ def main():
         if rank == 0:                      # minutes of set-up, plans and GEMM tuning before the first timed epoch
             print(f'[bench +{time.time() - t_start:.0f}s] {msg}', file=sys.stderr, flush=True)
     say(f'graph and model built ({t_build:.1f} s)')
+    import threading
+    warm = threading.Event()
+
+    def heartbeat():                       # the first epoch of a large shape can be minutes of plan building and GEMM
+        while not warm.wait(60.0):         # timing with nothing to say: tell whoever watches that the run is alive
+            say('still warming up (work plans, GEMM candidates)')
+    threading.Thread(target=heartbeat, daemon=True).start()
     for i in range(args.warmup):          # also builds the CSR blocks and work plans (once)
         step()
         torch.cuda.synchronize()
         say(f'warm-up epoch {i + 1} of {args.warmup} done')
+    warm.set()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

@@ -415,7 +415,7 @@ def main():
             "config": {"workload": f"{args.workload}-shape {layers}-layer {args.model}, hidden {args.hidden}, 1D row partition over {world} GPU(s)",
                        "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
                        "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),
-                       "gemm": 'torch.mm, TunableOp picks' if tuned else 'torch.mm, library defaults', "scale": args.scale},
+                       "gemm": {False: "torch.mm on PyTorch's default library", 'library': 'torch.mm; per shape the faster of rocBLAS / hipBLASLt (timed on first use)', 'full': 'torch.mm; per shape the TunableOp search (up to 100 GFLOP) or the faster library'}[tuned], "scale": args.scale},
             "roofline": roofline, "cpu_baseline": cpu, "gpu_ms_per_step": breakdown, "comm": comm, "alt": alt,
             "peak_device_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "final_loss": round(loss_val, 4), "final_loss_all_ranks": round(global_loss, 6), "setup_s": round(t_build, 1),
         }

@@ -6,5 +6,6 @@ from .env import DistEnv
 from .timer import DistTimer
 from .logger import DistLogger
 from .gemm import tune_gemms
+from . import gemm
 
-__all__ = ['DistEnv', 'DistTimer', 'DistLogger', 'tune_gemms']
+__all__ = ['DistEnv', 'DistTimer', 'DistLogger', 'tune_gemms', 'gemm']

@@ -21,7 +21,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from dist_utils import DistEnv
+from dist_utils import DistEnv, gemm as _gemm
 
 _spmm_override = None          # tests install the CPU oracle here to exercise the pipeline on gloo
 _gather_override = None
@@ -775,12 +775,12 @@ def grad_weight_product(features, ag):
     Same fp32 sums in a different association (8e-6 relative, measured); small blocks keep the single call."""
     n = features.size(0)
     if n < 65536 or not features.is_cuda:
-        return torch.mm(features.t(), ag)
+        return _gemm.mm(features.t(), ag)
     k = 4
     m = n // k * k
-    out = torch.bmm(features[:m].reshape(k, m // k, -1).transpose(1, 2), ag[:m].reshape(k, m // k, -1)).sum(0)
+    out = _gemm.bmm(features[:m].reshape(k, m // k, -1).transpose(1, 2), ag[:m].reshape(k, m // k, -1)).sum(0)
     if m < n:
-        out = out + torch.mm(features[m:].t(), ag[m:])
+        out = out + _gemm.mm(features[m:].t(), ag[m:])
     return out
 
 
@@ -823,13 +823,13 @@ class DistGCNLayer(torch.autograd.Function):
             # so it is off by default; the backward formulas below hold unchanged. The tag suffix keeps
             # this temporary out of the input-feature cache.
             with timer.timing_cuda('mm'):
-                hw = torch.mm(features, weight)
+                hw = _gemm.mm(features, weight)
             return broadcast(adj_parts, hw, 'Forward' + tag + 'T')
         z_local = broadcast(adj_parts, features, 'Forward' + tag, padded_out=True)
         if wgrad_from_z() and not ctx.needs_input_grad[0]:
             ctx.z_local = z_local                       # kept instead of re-deriving A_hat G in the backward pass
         with timer.timing_cuda('mm'):
-            return torch.mm(z_local, weight)
+            return _gemm.mm(z_local, weight)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -847,7 +847,7 @@ class DistGCNLayer(torch.autograd.Function):
         with DistEnv.env.timer.timing_cuda('mm'):
             # the input features of layer 1 need no gradient: skip that product (the reference computes
             # and discards it, gcn.py:49); every gradient that is used is unchanged
-            grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
+            grad_features = _gemm.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
             grad_weight = grad_weight_product(features, ag)
         with DistEnv.env.timer.timing_cuda('all_reduce'):
             DistEnv.env.all_reduce_sum(grad_weight)
@@ -868,14 +868,14 @@ def aggregation_layer(name, aggregate, forward_tag=lambda t: 'Forward' + t, back
             ctx.adj_parts, ctx.tag = adj_parts, tag
             z_local = aggregate(adj_parts, features, forward_tag(tag))
             with DistEnv.env.timer.timing_cuda('mm'):
-                return torch.mm(z_local, weight)
+                return _gemm.mm(z_local, weight)
 
         @staticmethod
         def backward(ctx, grad_output):
             features, weight = ctx.saved_tensors
             ag = aggregate(ctx.adj_parts, grad_output, backward_tag(ctx.tag))
             with DistEnv.env.timer.timing_cuda('mm'):
-                grad_features = torch.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
+                grad_features = _gemm.mm(ag, weight.t()) if ctx.needs_input_grad[0] else None
                 grad_weight = grad_weight_product(features, ag)
             with DistEnv.env.timer.timing_cuda('all_reduce'):
                 (reduce_grad or DistEnv.env.all_reduce_sum)(grad_weight)

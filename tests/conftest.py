@@ -22,7 +22,7 @@ def golden_dir():
 # under test they are filled with NaN first, so an element nobody stores cannot pass for a zero
 os.environ.setdefault('DGNN_POISON', '1')
 
-# dist_train.train() lets PyTorch time every library GEMM candidate per shape (dist_utils/gemm.py); with dozens of small
-# shapes and up to 8 test ranks on one GPU that is minutes of timing runs that check nothing. The suite runs on the
-# library's default kernels; test_train_gpu.py turns the tuner on in a child process for the golden loss curve.
+# dist_train.train() picks the library of every X W shape by timing (dist_utils/gemm.py): which one wins a tiny shape
+# varies from run to run, and tests that compare two runs bit for bit need the same kernels in both. The suite runs on
+# PyTorch's default library; test_train_gpu.py turns the choice on in child processes for the golden loss curve.
 os.environ.setdefault('DGNN_TUNE_GEMM', '0')

@@ -148,7 +148,10 @@ def test_gemm_tuner_and_row_pitch_helpers_without_a_gpu(monkeypatch):
     if torch.cuda.is_available():
         return                                          # (the GPU suite covers the other side)
     monkeypatch.setenv('DGNN_TUNE_GEMM', '1')
-    assert dist_utils.tune_gemms() is False and dist_utils.tune_gemms(True) is False     # (and touched no HIP call: there is no device)
+    assert dist_utils.tune_gemms() is False and dist_utils.tune_gemms(True) is False and dist_utils.tune_gemms('library') is False
+    assert dist_utils.gemm.picks() == {}              # (and no HIP call was made: there is no device)
+    a, b = torch.rand(6, 5), torch.rand(5, 4)
+    assert torch.equal(dist_utils.gemm.mm(a, b), torch.mm(a, b))        # CPU operands pass straight through
     x = torch.rand(5, 64)
     assert not spmm_cpp.is_row_padded(x) and spmm_cpp.padded_width(41) == 64 and spmm_cpp.padded_width(602) == 608
     try:

@@ -87,11 +87,16 @@ def test_layer_and_training_curve_on_gpu(env, golden_dir, name):
     losses = dist_train.train(pg, env, total_epoch=5)
     np.testing.assert_allclose(np.array(losses), w['r0_losses'], rtol=1e-4, atol=1e-4)           # curves overlay
     assert 'spmm' in env.timer.summary() and env.timer.count_dict['spmm'] > 0
+    import dist_utils
     import torch.cuda.tunable as tunable
-    if os.environ.get('DGNN_TUNE_GEMM') == '1':      # the child of test_golden_loss_curve_with_tuned_library_gemms
-        assert tunable.is_enabled() and len(tunable.get_results()) > 0
+    mode = os.environ.get('DGNN_TUNE_GEMM')               # '0' in the suite; the children of the tuned-GEMM test set it
+    kinds = set(dist_utils.gemm.picks().values())
+    if mode == 'library':                                  # per shape the faster library's default kernel
+        assert kinds and kinds <= {'cublas', 'cublaslt'} and not tunable.is_enabled()
+    elif mode == '1':                                      # small products: TunableOp's search
+        assert tunable.is_enabled() and len(tunable.get_results()) > 0 and kinds == {'tunableop'}
     else:
-        assert not tunable.is_enabled()
+        assert not kinds and not tunable.is_enabled()
 
 
 def test_cpu_tensors_fail_loudly_in_the_model_path(env):
@@ -255,24 +260,27 @@ def test_golden_layer_and_loss_curve_with_tiles_forced_on_small_blocks():
 
 
 def test_golden_loss_curve_with_tuned_library_gemms(tmp_path):
-    """dist_train.train() turns PyTorch's TunableOp on (dist_utils.tune_gemms: the fastest rocBLAS / hipBLASLt kernel per
-    X W shape). fp32 stays fp32, so the reference's loss curve must still hold at its tolerance whichever kernels win;
-    run in a child process because the tuner's switch is process-wide. The picks land in the cache directory, nowhere
-    else, and a second child reads them back (it must pass just the same)."""
+    """dist_train.train() chooses the library per X W shape by timing (dist_utils.gemm: the faster of the rocBLAS /
+    hipBLASLt defaults with DGNN_TUNE_GEMM=library; by default PyTorch's TunableOp search for products up to 100 GFLOP,
+    picks kept in the cache directory). fp32 stays fp32, so the reference's loss curve must still hold at its tolerance
+    whichever kernels win; run in child processes because the switches are process-wide: the library mode, the search
+    from scratch, the search with its picks read back. Nothing is written outside the cache directory, and nothing at
+    all in the library mode."""
     import glob
     import subprocess
     import sys
-    env = dict(os.environ, DGNN_TUNE_GEMM='1', DGNN_CACHE_DIR=str(tmp_path))
+    env = dict(os.environ, DGNN_CACHE_DIR=str(tmp_path))
     env.pop('PYTORCH_TUNABLEOP_FILENAME', None)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
         env.pop(k, None)
     before = set(glob.glob(os.path.join(ROOT, '*.csv')))
-    for attempt in range(2):
+    for mode in ('library', '1', '1'):
+        env['DGNN_TUNE_GEMM'] = mode
         r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider',
                             os.path.join(ROOT, 'tests', 'test_train_gpu.py'), '-k', 'layer_and_training_curve'],
                            env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
         assert ' passed' in r.stdout and 'failed' not in r.stdout
         files = glob.glob(os.path.join(str(tmp_path), 'tunableop*.csv'))
-        assert files and any('Gemm' in open(f).read() for f in files), files
+        assert any('Gemm' in open(f).read() for f in files) == (mode == '1'), files
     assert set(glob.glob(os.path.join(ROOT, '*.csv'))) == before

@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--hidden', type=int, default=256)
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--parts', default='1,2,4,8')
+    ap.add_argument('--no-tuner', action='store_true', help='stop after the per-library defaults')
     a = ap.parse_args()
     n, _, f_in, ncls = synthetic.SHAPES[a.shape][:4]
     dims = [f_in] + [a.hidden] * (a.layers - 1) + [ncls]
@@ -49,6 +50,18 @@ def main():
         w = torch.rand(k, m, device=dev) if kind == 'Z W' else torch.rand(m, k, device=dev).t()
         ops[(P, kind, s, k, m)] = (x, w)
     base = {key: timed(lambda: torch.mm(*xw)) for key, xw in ops.items()}
+    print('default library:', torch.backends.cuda.preferred_blas_library(), flush=True)
+    by_lib = {}
+    for lib in ('cublas', 'cublaslt'):                 # = rocBLAS / hipBLASLt on ROCm: each library's own default pick
+        torch.backends.cuda.preferred_blas_library(lib)
+        by_lib[lib] = {key: timed(lambda: torch.mm(*xw)) for key, xw in ops.items()}
+    torch.backends.cuda.preferred_blas_library('default')
+    for key in ops:
+        P, kind, s, k, m = key
+        print(f'P={P} {kind:6s} [{s} x {k}] [{k} x {m}]: default {base[key]:.3f} ms, rocBLAS {by_lib["cublas"][key]:.3f} ms, '
+              f'hipBLASLt {by_lib["cublaslt"][key]:.3f} ms', flush=True)
+    if a.no_tuner:
+        return
     t0 = time.time()
     assert dist_utils.tune_gemms(True)
     for key, xw in ops.items():

@@ -65,13 +65,13 @@ def main():
     t0 = time.time()
     assert dist_utils.tune_gemms(True)
     for key, xw in ops.items():
-        torch.mm(*xw)
+        dist_utils.gemm.mm(*xw)                       # the training path's entry: search or library choice per shape
         torch.cuda.synchronize()
-        print(f'tuned {key} after {time.time() - t0:.1f} s', flush=True)
+        print(f'chosen {key} after {time.time() - t0:.1f} s: {list(dist_utils.gemm.picks().values())[-1]}', flush=True)
     for key, xw in ops.items():
-        t = timed(lambda: torch.mm(*xw))
+        t = timed(lambda: dist_utils.gemm.mm(*xw))
         P, kind, s, k, m = key
-        print(f'P={P} {kind:6s} [{s} x {k}] [{k} x {m}]: default {base[key]:.3f} ms, tuned {t:.3f} ms', flush=True)
+        print(f'P={P} {kind:6s} [{s} x {k}] [{k} x {m}]: default {base[key]:.3f} ms, chosen {t:.3f} ms', flush=True)
 
 
 if __name__ == '__main__':

@@ -947,7 +947,10 @@ class DensePlan:
         pout = torch.where(pcut, (torch.cumsum(pcut.long(), 0) - 1) * TR, torch.full_like(plen, -1))
         maxlen = int(plen.max().item()) if plen.numel() else 0
         self.max_piece = maxlen
-        o2 = torch.argsort(pstart * (maxlen + 1) + (maxlen - plen), stable=True)
+        # whole (uncut) lists span every column and have no place in that order: they go last, where they fill the tail of
+        # the launch (measured against first / centre / end of their range: tiles -2 % at F = 602, -4 % at F = 256)
+        pkey = torch.where(nb_t[ptile] == 1, torch.full_like(pstart, m), pstart)
+        o2 = torch.argsort(pkey * (maxlen + 1) + (maxlen - plen), stable=True)
         self.desc = torch.stack([k0[pidx], k1[pidx], ptile, pout], dim=1)[o2].int().contiguous()
         self.npiece = int(self.desc.size(0))
         self.npartial = int(pcut.sum().item()) * TR

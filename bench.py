@@ -244,7 +244,9 @@ def main():
     env = dist_utils.DistEnv(rank, world, args.backend, echo=False)
     dev = env.device
     # as dist_train.train does: the picks are made in the warm-up epochs (not in the gloo rehearsal, where the ranks share a GPU)
-    tuned = dist_utils.tune_gemms(None if args.backend == 'nccl' else False)
+    # dist_train.train() leaves the GEMM library choice off by default (reproducible bits); the bench opts in, as a
+    # production run would with DGNN_TUNE_GEMM=1 (DGNN_TUNE_GEMM=0 python bench.py measures PyTorch's default library)
+    tuned = dist_utils.tune_gemms(os.environ.get('DGNN_TUNE_GEMM', '1') if args.backend == 'nccl' else False)
 
     t_build = t_start = time.time()
     g, n_nodes, nnz_total = build_rank_graph(args, env)

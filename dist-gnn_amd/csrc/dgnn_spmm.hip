@@ -916,6 +916,234 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Row strips: "feature tiles of H_j staged in LDS" (north_star), in the form that pays on graphs with hub columns.
+//
+// Every kernel above pulls one slice of a B row per nonzero (or per union entry of a few rows) through the texture-address
+// unit, which is what bounds them (64 B/clk/CU, L2 hit or not). Here a workgroup owns a ROW TILE of 256 rows (rows ranked
+// by length, 256 consecutive ranks: rows of similar length share the hub columns -- Reddit shape: the union of a tile's
+// columns is 0.15 of its nonzeros) and one 256-float feature chunk. The tile's union column list is walked in ascending
+// STRIPS of 64 columns; a strip's 64 slices of B (1 KiB each) go global -> LDS once, by LDS-DMA (global_load_lds_dwordx4:
+// no register staging), double-buffered: strip s + 1 travels while strip s is multiplied. Each of the 16 waves owns 16 rows
+// of the tile with all their accumulators in registers (a lane owns floats 2l, 2l+1 and 128+2l, 128+2l+1 of the chunk =
+// 4 registers per row, 64 in all) and walks ITS rows' entries of the strip: one flat list of (slot, row, value) per
+// (wave, strip), no zero padding of the matrix. Per entry and wave: two ds_read_b64 at slot * 2 KiB + lane * 8 (conflict
+// free: the LDS image of a slice is the B row in its own order) and two v_pk_fma_f32. What makes a flat list possible is
+// the accumulator ROW being data: the FMAs run in VGPR index mode (s_set_gpr_idx_on: M0[7:0] is added to the register
+// number of dst and src2), so acc[row] += val * b is ONE instruction for a wave-uniform dynamic row.
+//   Entries reach the wave through ONE coalesced vector load per strip (lane k holds entry k of the wave's block, fetched a
+// whole strip ahead; vector memory returns in order, so the wait is counted -- scalar loads share a counter with the LDS and
+// return out of order, which forbids running ahead of them) and are broadcast with v_readlane_b32 into an SGPR pair
+// {slot << 11 | row * 4, value}: the pair is the first operand of the packed FMA as it stands (op_sel picks the value for
+// both halves), its low byte is the register index, (pair.x & ~0x1ff) | lane base is the LDS address.
+//   The inner loop is inline assembly on pinned registers (accumulators v[64:127], scratch v[24:47], s[36:43]): the compiler
+// cannot express index mode, and a register tuple operand cannot be split into the pairs the instructions need.
+//   Per row the entries come in ascending column order (strips ascend, a block is sorted by row then column) and the chain
+// starts from what C holds: rows of uncut tiles carry the bits of the strict chain. A tile whose union list is longer than
+// the plan's piece length is cut at strip boundaries into pieces (partial rows, merged per row in piece order).
+// Pad entries (blocks are padded to whole groups of 4) carry the value -0.0 and the slot of an all-zero slice:
+// fma(-0.0, +0.0, acc) == acc for every acc, signed zeros and NaN included -- nothing is changed by them.
+// No MFMA, no atomics.
+// ---------------------------------------------------------------------------------------
+constexpr int STRIP_W = 64;                    // union columns per strip, at most (a piece may use 8, 16 or 32)
+constexpr int STRIP_NW = 16;                   // waves per workgroup
+constexpr int STRIP_RW = 16;                   // rows per wave
+constexpr int STRIP_R = STRIP_NW * STRIP_RW;   // rows per tile
+constexpr int STRIP_CH = 256;                  // floats per feature chunk
+constexpr int STRIP_LDS_B = (STRIP_W + 1) * 2048;   // slot s of buffer q at (2 s + q) KiB; slot STRIP_W holds zeros
+constexpr int STRIP_LINE = 32;                 // entries of a line of a wave's entry stream (256 B = one LDS-DMA instruction)
+constexpr int STRIP_RING = 3;                  // lines a wave holds in LDS: in use, next, the one after
+constexpr int STRIP_LDS = STRIP_LDS_B + STRIP_NW * STRIP_RING * STRIP_LINE * 8;
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// one group of 4 entries: entry k of the line sits in lanes 2k (slot << 11 | row * 4 [| header]) and 2k + 1 (value) of v28
+#define STRIP_RL(S, L) "v_readlane_b32 s" #S ", v28, " #L "\n\t"
+#define STRIP_FMA(S0, S1, VLO0, VLO1, VHI0, VHI1)                                                                    \
+  "v_pk_fma_f32 v[64:65], s[" #S0 ":" #S1 "], v[" #VLO0 ":" #VLO1 "], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+  "v_pk_fma_f32 v[66:67], s[" #S0 ":" #S1 "], v[" #VHI0 ":" #VHI1 "], v[66:67] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define STRIP_GROUP_HEAD(L0, L1, L2, L3, L4, L5, L6, L7)                                                             \
+  STRIP_RL(36, L0) STRIP_RL(37, L1) STRIP_RL(38, L2) STRIP_RL(39, L3)                                                \
+  STRIP_RL(40, L4) STRIP_RL(41, L5) STRIP_RL(42, L6) STRIP_RL(43, L7)
+#define STRIP_GROUP_BODY(NEXT)                                                                                       \
+  "v_and_or_b32 v24, s36, %[mask], %[lb]\n\t"                                                                        \
+  "v_and_or_b32 v25, s38, %[mask], %[lb]\n\t"                                                                        \
+  "v_and_or_b32 v26, s40, %[mask], %[lb]\n\t"                                                                        \
+  "v_and_or_b32 v27, s42, %[mask], %[lb]\n\t"                                                                        \
+  "ds_read_b64 v[32:33], v24\n\t"                                                                                    \
+  "ds_read_b64 v[34:35], v24 offset:512\n\t"                                                                         \
+  "ds_read_b64 v[36:37], v25\n\t"                                                                                    \
+  "ds_read_b64 v[38:39], v25 offset:512\n\t"                                                                         \
+  "ds_read_b64 v[40:41], v26\n\t"                                                                                    \
+  "ds_read_b64 v[42:43], v26 offset:512\n\t"                                                                         \
+  "ds_read_b64 v[44:45], v27\n\t"                                                                                    \
+  "ds_read_b64 v[46:47], v27 offset:512\n\t"                                                                         \
+  "s_set_gpr_idx_on s36, 0xc\n\t"                                                                                    \
+  "s_waitcnt lgkmcnt(6)\n\t" STRIP_FMA(36, 37, 32, 33, 34, 35)                                                       \
+  "s_set_gpr_idx_idx s38\n\t"                                                                                        \
+  "s_waitcnt lgkmcnt(4)\n\t" STRIP_FMA(38, 39, 36, 37, 38, 39)                                                       \
+  "s_set_gpr_idx_idx s40\n\t"                                                                                        \
+  "s_waitcnt lgkmcnt(2)\n\t" STRIP_FMA(40, 41, 40, 41, 42, 43)                                                       \
+  "s_set_gpr_idx_idx s42\n\t"                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n\t" STRIP_FMA(42, 43, 44, 45, 46, 47)                                                       \
+  "s_set_gpr_idx_off\n\t"                                                                                            \
+  "s_cmp_eq_u32 s44, " #NEXT "\n\t"                                                                                  \
+  "s_cbranch_scc1 9f\n\t"
+
+// Multiply the line at LDS address `ra` (lane l: dword l of the line) into the accumulators. The line's first entry
+// carries the header: bits 20-23 the groups of 4 entries to take (1..8), bit 24 "last line of this strip". Returns bit 24.
+__device__ __forceinline__ uint32_t strip_line(f32x32& accA, f32x32& accB, uint32_t ra, uint32_t lb) {
+  const uint32_t mask = 0x0003fe00u;
+  uint32_t last;
+  asm volatile(
+      "ds_read_b32 v28, %[ra]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      STRIP_GROUP_HEAD(0, 1, 2, 3, 4, 5, 6, 7)
+      "s_bfe_u32 s44, s36, 0x40014\n\t"                        // groups in this line
+      "s_bfe_u32 %[last], s36, 0x10018\n\t"
+      STRIP_GROUP_BODY(1)
+      STRIP_GROUP_HEAD(8, 9, 10, 11, 12, 13, 14, 15) STRIP_GROUP_BODY(2)
+      STRIP_GROUP_HEAD(16, 17, 18, 19, 20, 21, 22, 23) STRIP_GROUP_BODY(3)
+      STRIP_GROUP_HEAD(24, 25, 26, 27, 28, 29, 30, 31) STRIP_GROUP_BODY(4)
+      STRIP_GROUP_HEAD(32, 33, 34, 35, 36, 37, 38, 39) STRIP_GROUP_BODY(5)
+      STRIP_GROUP_HEAD(40, 41, 42, 43, 44, 45, 46, 47) STRIP_GROUP_BODY(6)
+      STRIP_GROUP_HEAD(48, 49, 50, 51, 52, 53, 54, 55) STRIP_GROUP_BODY(7)
+      STRIP_GROUP_HEAD(56, 57, 58, 59, 60, 61, 62, 63) STRIP_GROUP_BODY(8)
+      "9:\n\t"
+      : "+{v[64:95]}"(accA), "+{v[96:127]}"(accB), [last] "=&s"(last)
+      : [ra] "v"(ra), [mask] "v"(mask), [lb] "v"(lb)
+      : "v24", "v25", "v26", "v27", "v28", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",
+        "v44", "v45", "v46", "v47", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "scc", "memory");
+  return last;
+}
+
+__global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
+    const int32_t* __restrict__ desc, int32_t npiece, const int32_t* __restrict__ rows, const int32_t* __restrict__ ucol,
+    const uint32_t* __restrict__ ent, const int64_t* __restrict__ ebase,
+    const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+    float* __restrict__ P, int64_t ldp, int32_t F, int vw2, int dbg) {
+  __shared__ __align__(16) unsigned char lds[STRIP_LDS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // chunk-major: the whole chip works on one 256-float chunk of B at a time (1 KiB x columns: what the Infinity Cache
+  // and the L2s then hold), pieces longest first inside a chunk
+  const int chunk = blockIdx.x / npiece, piece = blockIdx.x - chunk * npiece;
+  const int32_t* const d = desc + (int64_t)piece * 8;          // {tile, k0, k1, out, strips, columns per strip, 0, 0}
+  const int tile = d[0], k0 = d[1], k1 = d[2], out = d[3], nsp = d[4], Wt = d[5];
+  const bool direct = out < 0;
+  const int f0 = chunk * STRIP_CH + lane * 2, f1 = f0 + 128;   // the lane's two float pairs
+  const bool act0 = f0 < (int)ldb, act1 = f1 < (int)ldb;       // ldb is a multiple of 32: a pair is inside the row or outside
+  const bool v2 = vw2 != 0;
+  const int32_t* const rw = rows + (int64_t)tile * STRIP_R;
+
+  if (threadIdx.x < 128)                                       // the all-zero slice pad entries point at (both buffers)
+    *reinterpret_cast<float4*>(lds + STRIP_W * 2048 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x32 accA, accB;                                           // row j of the wave: registers 4 j .. 4 j + 3 = {lo.x, lo.y, hi.x, hi.y}
+#pragma unroll
+  for (int j = 0; j < STRIP_RW; ++j) {
+    f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+    if (direct) {
+      const int row = rw[j * STRIP_NW + wave];
+      if (row >= 0) {
+        if (act0) lo = c2_load(C + (int64_t)row * ldc + f0, f0, F, v2);
+        if (act1) hi = c2_load(C + (int64_t)row * ldc + f1, f1, F, v2);
+      }
+    }
+    if (j < 8) { accA[4 * j] = lo.x; accA[4 * j + 1] = lo.y; accA[4 * j + 2] = hi.x; accA[4 * j + 3] = hi.y; }
+    else { accB[4 * j - 32] = lo.x; accB[4 * j - 31] = lo.y; accB[4 * j - 30] = hi.x; accB[4 * j - 29] = hi.y; }
+  }
+  __syncthreads();                                             // the zero slice is in place; C has been read
+
+  // From here on every vector-memory operation of the wave is an LDS-DMA (nothing lands in a register, so the compiler
+  // inserts no waits of its own) and the waits are counted by hand: vector memory completes in order, a step ends by
+  // requesting the entry line two steps ahead (one instruction), and the next step starts with vmcnt(1) -- everything
+  // but that youngest request has landed: the slices of the strip about to be multiplied and the line about to be read.
+  // The wave's entry stream is a sequence of 256-byte lines (32 entries; a block = the entries of one strip = whole lines),
+  // so the requests simply walk it; what a line holds is in its header. Column ids come through the scalar cache
+  // (wave-uniform, requested a strip ahead).
+  const char* const Bb = reinterpret_cast<const char*>(B) + (int64_t)chunk * (STRIP_CH * 4) + lane * 16;
+  const bool dma = chunk * STRIP_CH + lane * 4 < (int)ldb && !(dbg & 2);     // lanes past the padded width move nothing
+  const uint64_t ldb_bytes = (uint64_t)ldb * 4u;
+  const int wslot = wave * 4;                                  // wave w moves slots 4 w .. 4 w + 3 of a strip
+  const int kw = k0 + wslot;
+  // (one 1-KiB instruction per slice: lane l copies floats 4l .. 4l+3, so the LDS image is the slice in its own order)
+#define STRIP_FILL(S, C0, C1, C2, C3)                                                                                   \
+  {                                                                                                                     \
+    const int kk = kw + (S) * Wt;                                                                                       \
+    unsigned char* const dst = lds + (2 * wslot + ((S) & 1)) * 1024;                                                    \
+    if (wslot + 0 < Wt && kk + 0 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C0) * ldb_bytes), (lds_void_ptr)(dst), 16, 0, 0);        \
+    if (wslot + 1 < Wt && kk + 1 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C1) * ldb_bytes), (lds_void_ptr)(dst + 2048), 16, 0, 0); \
+    if (wslot + 2 < Wt && kk + 2 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C2) * ldb_bytes), (lds_void_ptr)(dst + 4096), 16, 0, 0); \
+    if (wslot + 3 < Wt && kk + 3 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C3) * ldb_bytes), (lds_void_ptr)(dst + 6144), 16, 0, 0); \
+  }
+#define STRIP_COLS(S, C0, C1, C2, C3)                                                                                   \
+  {                                                                                                                     \
+    const int kk = kw + (S) * Wt;                              /* clamped: slots nobody uses repeat a column */          \
+    C0 = ucol[min(max(kk + 0, k0), k1 - 1)]; C1 = ucol[min(max(kk + 1, k0), k1 - 1)];                                   \
+    C2 = ucol[min(max(kk + 2, k0), k1 - 1)]; C3 = ucol[min(max(kk + 3, k0), k1 - 1)];                                   \
+  }
+  const uint32_t* lp = ent + ebase[(int64_t)piece * STRIP_NW + wave] * (STRIP_LINE * 2) + lane;   // next line to request, this lane's dword
+  unsigned char* const ring = lds + STRIP_LDS_B + wave * (STRIP_RING * STRIP_LINE * 8);
+  const uint32_t ring_ra = (uint32_t)(STRIP_LDS_B + wave * (STRIP_RING * STRIP_LINE * 8) + lane * 4);
+  int c0, c1, c2, c3;
+  STRIP_COLS(0, c0, c1, c2, c3)
+  STRIP_FILL(0, c0, c1, c2, c3)
+  STRIP_COLS(1, c0, c1, c2, c3)
+  __builtin_amdgcn_global_load_lds((const void*)lp, (lds_void_ptr)(ring), 4, 0, 0);
+  lp += STRIP_LINE * 2;
+  __builtin_amdgcn_global_load_lds((const void*)lp, (lds_void_ptr)(ring + STRIP_LINE * 8), 4, 0, 0);
+  lp += STRIP_LINE * 2;
+  int rs = 0, ws = 2;                                          // ring slot to read / to request into
+  int s = 0;
+  uint32_t first = 1;
+#pragma unroll 1
+  while (s < nsp) {
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");            // all but the youngest line request have landed
+    if (first) {
+      __builtin_amdgcn_s_barrier();                             // everybody's slices of s are in; everybody is done with s - 1
+      if (s + 1 < nsp) STRIP_FILL(s + 1, c0, c1, c2, c3)
+      STRIP_COLS(s + 2, c0, c1, c2, c3)
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_global_load_lds((const void*)lp, (lds_void_ptr)(ring + ws * (STRIP_LINE * 8)), 4, 0, 0);
+    lp += STRIP_LINE * 2;
+    ws = ws == STRIP_RING - 1 ? 0 : ws + 1;
+    const uint32_t lb = (uint32_t)lane * 8u + (uint32_t)(s & 1) * 1024u;
+    uint32_t last = 1;
+    if (!(dbg & 1)) last = strip_line(accA, accB, ring_ra + rs * (STRIP_LINE * 8), lb);
+    else {                                                      // (timing experiments: read the header only)
+      const uint32_t h = *reinterpret_cast<const volatile uint32_t*>(ring + rs * (STRIP_LINE * 8));
+      last = (__builtin_amdgcn_readfirstlane(h) >> 24) & 1u;
+    }
+    rs = rs == STRIP_RING - 1 ? 0 : rs + 1;
+    first = last;
+    s += (int)last;
+  }
+#undef STRIP_FILL
+#undef STRIP_COLS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the last requests land before the LDS goes back
+
+#pragma unroll
+  for (int j = 0; j < STRIP_RW; ++j) {
+    const int i = j * STRIP_NW + wave;
+    const int row = rw[i];
+    if (row < 0) continue;
+    f32x2 lo, hi;
+    if (j < 8) { lo = (f32x2){accA[4 * j], accA[4 * j + 1]}; hi = (f32x2){accA[4 * j + 2], accA[4 * j + 3]}; }
+    else { lo = (f32x2){accB[4 * j - 32], accB[4 * j - 31]}; hi = (f32x2){accB[4 * j - 30], accB[4 * j - 29]}; }
+    if (direct) {
+      if (act0) c2_store(C + (int64_t)row * ldc + f0, f0, F, v2, lo);
+      if (act1) c2_store(C + (int64_t)row * ldc + f1, f1, F, v2, hi);
+    } else {
+      float* const pp = P + (int64_t)(out + i) * ldp;
+      if (f0 < ldp) *reinterpret_cast<float2*>(pp + f0) = make_float2(lo.x, lo.y);
+      if (f1 < ldp) *reinterpret_cast<float2*>(pp + f1) = make_float2(hi.x, hi.y);
+    }
+  }
+}
+
 // C[row] += partial[pbase] + partial[pbase+1] + ...  (fixed order). One wave per (cut run, 256-float chunk); a lane owns
 // one float4 column of the (16-B aligned, padded) partial rows and keeps 4 piece loads in flight (16 measured slower:
 // the merges are thousands of short runs, bound by their traffic, not by a chain of round trips).
@@ -1373,7 +1601,7 @@ size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" {
 
-int dgnn_version(void) { return 250; }   // 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
+int dgnn_version(void) { return 260; }   // 260: dgnn_strip_plan, dgnn_spmm_strip_f32; 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 
@@ -1705,6 +1933,46 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
     ProfScope prof(s, 1);
     const int4* cutp = reinterpret_cast<const int4*>(plan->cut);
     launch_merge(vwc, cutp, plan->ncut, partial, ldp, C, ldc, F, 0, s);
+    DGNN_HIP(hipGetLastError());
+  }
+  return DGNN_OK;
+}
+
+int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                        int32_t F, float alpha, void* stream) {
+  if (!plan) return fail(DGNN_E_BADARG, "spmm_strip: null plan%s", "");
+  if (plan->rows_per_tile != STRIP_R || plan->strip_cols != STRIP_W || plan->waves != STRIP_NW || plan->line_entries != STRIP_LINE)
+    return fail(DGNN_E_BADARG, "spmm_strip: plan geometry must be 256 rows per tile, at most 64 columns per strip, 16 waves, 32 entries per line%s", "");
+  if (n < 0 || m < 0 || F < 0 || plan->npiece < 0 || plan->ncut < 0 || plan->ntile < 0)
+    return fail(DGNN_E_BADARG, "spmm_strip: negative size%s", "");
+  if (n == 0 || F == 0 || plan->npiece == 0) return DGNN_OK;
+  if (alpha != 1.f) return fail(DGNN_E_BADARG, "spmm_strip: only alpha == 1 (the values go into the FMAs as stored)%s", "");
+  if (!C || ldc < F) return fail(DGNN_E_BADARG, "spmm_strip: bad C%s", "");
+  if (!plan->desc || !plan->rows || !plan->ucol || !plan->ent || !plan->ebase || !B)
+    return fail(DGNN_E_BADARG, "spmm_strip: null pointer%s", "");
+  if (ldb < F || ldb % 32 != 0 || !aligned(B, 16) || !aligned(plan->ent, 8))
+    return fail(DGNN_E_BADARG, "spmm_strip: B needs ldb >= F, ldb %% 32 == 0 and a 16-byte aligned base (dgnn_pad_rows_f32 at the padded pitch)%s", "");
+  if (plan->ncut > 0 && (!partial || !plan->cut || ldp < ldb || ldp % 4 != 0 || !aligned(partial, 16)))
+    return fail(DGNN_E_BADARG, "spmm_strip: cut tiles need a 16-byte aligned partial buffer with ldp >= ldb, ldp %% 4 == 0%s", "");
+  if (overlap(B, m, ldb, C, n, ldc, F)) return fail(DGNN_E_BADARG, "spmm_strip: B and C overlap%s", "");
+  if (ldb >= (1ll << 30)) return fail(DGNN_E_BADARG, "spmm_strip: ldb out of range%s", "");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nchunk = (ldb + STRIP_CH - 1) / STRIP_CH;
+  const int64_t nitems = (int64_t)plan->npiece * nchunk;
+  if (nitems > 0x7fffffffLL) return fail(DGNN_E_BADARG, "spmm_strip: grid out of range%s (%lld)", "", nitems);
+  const int vw2 = (ldc % 2 == 0 && aligned(C, 8)) ? 1 : 0;
+  const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : (vw2 ? 2 : 1);
+  {
+    ProfScope prof(s, 0);
+    hipLaunchKernelGGL(spmm_strip_kernel, dim3((unsigned)nitems), dim3(STRIP_NW * 64), 0, s, plan->desc, plan->npiece, plan->rows,
+                       plan->ucol, plan->ent, plan->ebase, B, ldb, C, ldc, partial, ldp, F, vw2,
+                       g_variant >= 500 && g_variant < 504 ? g_variant - 500 : 0);
+    DGNN_HIP(hipGetLastError());
+  }
+  if (plan->ncut > 0) {
+    ProfScope prof(s, 1);
+    launch_merge(vwc, reinterpret_cast<const int4*>(plan->cut), plan->ncut, partial, ldp, C, ldc, F, 0, s);
     DGNN_HIP(hipGetLastError());
   }
   return DGNN_OK;

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from coo_graph import Parted_COO_Graph
-from dist_utils import tune_gemms
+from dist_utils import tune_gemms, gemm
 from models import GCN, CachedGCN
 
 
@@ -83,8 +83,18 @@ def train_step(model, optimizer, loss_func, g, env):
 
 
 def train(g, env, total_epoch, model='GCN', hidden_dim=256, num_layers=3, lr=0.01, eval_every=10):
-    if env.device.type == 'cuda':
-        tune_gemms()                 # the X W products: fastest library kernel per shape, found in the first epoch
+    # The X W products stay on PyTorch's default BLAS library unless DGNN_TUNE_GEMM=1|library asks for the per-shape
+    # choice (dist_utils/gemm.py): a timing race decides it, so the default run reproduces bits like the reference's
+    # plain torch.mm. Only with real GPUs per rank (nccl): under the gloo rehearsal the ranks share one card.
+    tuned = tune_gemms() if (env.device.type == 'cuda' and getattr(env, 'backend', 'nccl') == 'nccl') else False
+    try:
+        return _train(g, env, total_epoch, model, hidden_dim, num_layers, lr, eval_every)
+    finally:
+        if tuned:
+            gemm.restore()           # PyTorch's global BLAS settings as the caller had them
+
+
+def _train(g, env, total_epoch, model, hidden_dim, num_layers, lr, eval_every):
     net = build_model(g, env, model, hidden_dim, num_layers)
     optimizer = torch.optim.Adam(net.parameters(), lr=lr)
     loss_func = cross_entropy_mean if g.labels.dim() == 1 else nn.BCEWithLogitsLoss(reduction='mean')

@@ -13,13 +13,17 @@ WHICH library kernel serves a shape, once per shape, by timing:
 Reddit-shape epoch: GEMMs 1.81 ms on PyTorch's default library, 1.60 with the library choice, 1.42 with the search;
 products shape: 16.2 / 15.7 / 14.8 (search up to 100 GFLOP) / 12.3 (search on every shape). fp32 stays fp32: only the
 kernel changes, so results move within rounding, as between library versions. DGNN_TUNE_GEMM=0 leaves everything to
-PyTorch's default library."""
+PyTorch's default library -- and that is the default of `dist_train.train()`: which kernel wins a timing race can differ
+from run to run and from rank to rank, so a run that must reproduce bits (the reference's plain torch.mm does) keeps the
+default library; bench.py and `DGNN_TUNE_GEMM=1|library python main.py ...` opt in. Picks of TunableOp go to one file per
+GLOBAL rank (ranks that each see their GPU as ordinal 0 would otherwise share a file), and `restore()` puts PyTorch's
+global BLAS settings back as they were."""
 import os
 import tempfile
 
 import torch
 
-_state = {'mode': None, 'picks': {}, 'lib': None, 'tuning': None}
+_state = {'mode': None, 'picks': {}, 'lib': None, 'tuning': None, 'saved': None}
 
 
 def _cache_dir():
@@ -36,12 +40,13 @@ def _cache_dir():
 
 def tune_gemms(on=None):
     """Switch the per-shape choice on for this process (training drivers call this once, before the first epoch).
-    ``on``: None = what DGNN_TUNE_GEMM says (default '1' = 'full'), False, True or 'full', 'library'. In 'full' mode TunableOp's picks go to
-    <DGNN_CACHE_DIR or ~/.cache/dgnn_spmm>/tunableop<device>.csv as they are made (PyTorch checks its own and the
-    libraries' versions when it reads them back; PYTORCH_TUNABLEOP_FILENAME names another file). Returns the mode:
-    False, 'library' or 'full'."""
+    ``on``: None = what DGNN_TUNE_GEMM says (default '0' = off: PyTorch's default library, reproducible bits), False,
+    True or 'full', 'library'. In 'full' mode TunableOp's picks go to
+    <DGNN_CACHE_DIR or ~/.cache/dgnn_spmm>/tunableop_rank<global rank><device>.csv as they are made (PyTorch checks its
+    own and the libraries' versions when it reads them back; PYTORCH_TUNABLEOP_FILENAME names another file). Returns the
+    mode: False, 'library' or 'full'. `restore()` undoes it."""
     if on is None:
-        on = os.environ.get('DGNN_TUNE_GEMM', '1')
+        on = os.environ.get('DGNN_TUNE_GEMM', '0')
     mode = {'0': False, False: False, '1': 'full', True: 'full', 'full': 'full', 'library': 'library'}.get(on)
     if mode is None:
         raise ValueError(f'DGNN_TUNE_GEMM={on!r}: expected 0, 1 (= full) or library')
@@ -49,15 +54,33 @@ def tune_gemms(on=None):
         return False
     if _state['mode']:
         return _state['mode']
+    saved = {'lib': torch.backends.cuda.preferred_blas_library()}
     if mode == 'full':
         import torch.cuda.tunable as tunable
+        saved.update(enabled=tunable.is_enabled(), tuning=tunable.tuning_is_enabled())
         if 'PYTORCH_TUNABLEOP_FILENAME' not in os.environ:
-            tunable.set_filename(os.path.join(_cache_dir(), 'tunableop.csv'), True)    # True: one file per device ordinal
+            # one file per global rank AND device ordinal: under per-rank HIP_VISIBLE_DEVICES every rank's GPU is ordinal 0
+            rank = os.environ.get('RANK', '0')
+            tunable.set_filename(os.path.join(_cache_dir(), f'tunableop_rank{rank}_.csv'), True)
         tunable.enable(True)
         tunable.tuning_enable(False)       # switched on per call, for the shapes that get the search
         _state['tuning'] = False
-    _state.update(mode=mode, lib=None, picks={})
+    _state.update(mode=mode, lib=None, picks={}, saved=saved)
     return mode
+
+
+def restore():
+    """Undo tune_gemms(): PyTorch's preferred BLAS library and TunableOp switches as they were before it; the per-shape
+    picks of this module are forgotten (TunableOp's file keeps its own)."""
+    saved = _state['saved']
+    if saved is None:
+        return
+    if 'enabled' in saved:
+        import torch.cuda.tunable as tunable
+        tunable.tuning_enable(saved['tuning'])
+        tunable.enable(saved['enabled'])
+    torch.backends.cuda.preferred_blas_library(saved['lib'])
+    _state.update(mode=None, lib=None, picks={}, tuning=None, saved=None)
 
 
 def picks():

@@ -51,6 +51,13 @@ class _CDensePlan(ctypes.Structure):     # struct dgnn_dense_plan (include/dgnn_
                 ('kcol', _p), ('kval', _p), ('cut', _p), ('nk', _i64), ('npartial', _i64)]
 
 
+class _CStripPlan(ctypes.Structure):     # struct dgnn_strip_plan (include/dgnn_spmm.h)
+    _fields_ = [('rows_per_tile', _i32), ('strip_cols', _i32), ('waves', _i32), ('line_entries', _i32), ('ntile', _i32),
+                ('npiece', _i32), ('ncut', _i32), ('reserved', _i32),
+                ('desc', _p), ('rows', _p), ('ucol', _p), ('ent', _p), ('ebase', _p), ('cut', _p),
+                ('nu', _i64), ('nline', _i64), ('npartial', _i64)]
+
+
 class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn_spmm.h)
     _fields_ = [('nstage', _i32), ('piece', _i32), ('hdr_ints', _i64), ('nseg_max', _i64), ('ncut_max', _i64),
                 ('npartial_max', _i64), ('ws_ints', _i64)]
@@ -79,13 +86,14 @@ _SIGNATURES = {                          # argument types, in the order of inclu
     'dgnn_spmm_plan_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
     'dgnn_spmm_bundle_f32': [ctypes.POINTER(_CBundlePlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
     'dgnn_spmm_dense_f32': [ctypes.POINTER(_CDensePlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
+    'dgnn_spmm_strip_f32': [ctypes.POINTER(_CStripPlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
     'dgnn_spmm_plan_overwrite_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
 }
 for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_ABI = 250                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+_ABI = 260                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
 if _lib.dgnn_version() != _ABI:
     raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
                        'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')
@@ -546,6 +554,16 @@ def _plan_for(A, F):
     # 1.16 ms against 1.49 ms for the whole block on the stage kernel).
     if padded_width(F) >= 128 and not int(os.environ.get('DGNN_HOT_ROWS', 0) or 0) \
             and os.environ.get('DGNN_PLAN_BUILDER', 'torch') != 'device':
+        # Row strips (StripPlan): tiles of 256 rows whose union column list is streamed once through LDS -- one B slice
+        # per (tile, column) instead of one gather per nonzero. Takes precedence over dense tiles and bundles where the
+        # rows share enough columns; what it leaves (the tail of short rows) goes through the plans below.
+        S = _strip_for(A)
+        if S is not None:
+            hp = A.__dict__.setdefault('_strip_hybrid', {})
+            rest_plan = _plan_for_sparse(S.rest, F)
+            if id(rest_plan) not in hp:
+                hp[id(rest_plan)] = StripHybridPlan(S, rest_plan)
+            return hp[id(rest_plan)]
         D = _dense_for(A)
         if D is not None:
             hp = A.__dict__.setdefault('_hybrid', {})
@@ -667,6 +685,12 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
         raise RuntimeError('spmm_plan: operands are on different devices')
     if plan is None:
         plan = _plan_for(A, F)
+    if isinstance(plan, StripHybridPlan):                # the rest first (it owns beta / overwrite and lists every row), then the strips
+        if float(alpha) != 1.0:
+            raise RuntimeError('spmm_plan: row-strip plans multiply with alpha == 1 only')
+        spmm_plan(plan.strip.rest, B, C, alpha, beta, plan=plan.rest_plan, overwrite=overwrite)
+        spmm_strip(plan.strip, B, C)
+        return
     if isinstance(plan, HybridPlan):                     # sparse remainder first (it owns beta / overwrite), then the tiles
         spmm_plan(plan.dense.rest, B, C, alpha, beta, plan=plan.rest_plan, overwrite=overwrite)
         spmm_dense(plan.dense, B, C, alpha)
@@ -1018,6 +1042,246 @@ def spmm_dense(D, B, C, alpha=1.0):
         with torch.cuda.device(dev):
             rc = _lib.dgnn_spmm_dense_f32(*args, _stream(C))
     _check(rc, 'spmm_dense')
+
+
+# --------------------------------------------------------------------------- row strips (B slices staged in LDS)
+STRIP_R, STRIP_NW, STRIP_W, STRIP_LINE = 256, 16, 64, 32     # rows per tile, waves per workgroup, widest strip, entries per line (the kernel's geometry)
+
+
+class StripPlan:
+    """``struct dgnn_strip_plan`` for one CsrBlock, plus what is left of the block (``self.rest``).
+
+    Rows are ranked by length and taken 256 at a time (a tile: rows of similar length share the hub columns). A tile
+    whose union of columns is at most ``max_ratio`` of its nonzeros is *selected*: its entries leave the CSR block and
+    are laid out for ``spmm_strip_kernel`` -- the tile's union column list (``ucol``) is walked in strips of W columns
+    whose B slices go through LDS once (W = 64, or 32 / 16 / 8 for tiles whose rows are so long that a wave's share of a
+    64-column strip would not fit one line); wave w of the workgroup owns members w, w + 16, ... of the tile and reads,
+    per strip, one block of (slot, row, value) entries sorted by row then column, stored as whole lines of 32 entries
+    (``ent``; a line's first entry carries how many groups of 4 to take and whether the block ends with it). Tiles with
+    poorer reuse (the tail of short rows) stay in ``self.rest``, a CsrBlock for the other plans. A union list longer than
+    ``piece_strips`` strips is cut into pieces (partial rows, merged in piece order). Integer work with torch ops on the
+    block's device, once per block.
+
+    ``share``: fraction of the block's nonzeros in selected tiles; ``union_ratio``: B slices fetched per nonzero there;
+    ``padding``: entry slots streamed per nonzero.
+    """
+
+    def __init__(self, A, max_ratio=None, piece_strips=None, min_tile_nnz=None, block_target=None):
+        R, NW, WMAX, LINE = STRIP_R, STRIP_NW, STRIP_W, STRIP_LINE
+        RW = R // NW
+        dev = A.device
+        n, m, nnz = A.n, A.m, A.nnz
+        if max_ratio is None:
+            max_ratio = float(os.environ.get('DGNN_STRIP_MAX_RATIO', 0.5))
+        if piece_strips is None:
+            piece_strips = int(os.environ.get('DGNN_STRIP_PIECE', 256))
+        if min_tile_nnz is None:
+            min_tile_nnz = int(os.environ.get('DGNN_STRIP_MIN_TILE_NNZ', 1024))
+        if block_target is None:
+            block_target = float(os.environ.get('DGNN_STRIP_BLOCK', 26))
+        if piece_strips < 1:
+            raise ValueError('piece_strips must be positive')
+        self.max_ratio, self.piece_strips = float(max_ratio), int(piece_strips)
+        i64 = dict(dtype=torch.long, device=dev)
+        rp = A.rowptr.long()
+        deg = rp[1:] - rp[:-1]
+        ntile = max(1, -(-n // R))
+        order = torch.argsort(deg, descending=True, stable=True)
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(n, **i64)
+        row_idx = torch.repeat_interleave(torch.arange(n, **i64), deg)
+        rnk = rank[row_idx]
+        tile = rnk // R
+        col = A.col.long()
+        ukey, inv = torch.unique(tile * m + col, return_inverse=True)           # sorted: by tile, then column
+        utile = ukey // m
+        usz = torch.bincount(utile, minlength=ntile)
+        ssz = torch.bincount(tile, minlength=ntile)
+        ok_t = (ssz >= max(int(min_tile_nnz), 1)) & (usz.double() <= self.max_ratio * ssz.double())
+        sel_u, sel_e = ok_t[utile], ok_t[tile]
+        # what stays: a CsrBlock of its own (whole rows: a tile is taken or left as a whole)
+        keep = ~sel_e
+        rest_rp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        rest_rp[1:] = torch.cumsum(torch.bincount(row_idx[keep], minlength=n), 0).int()
+        self.rest = CsrBlock(n, m, rest_rp, A.col[keep].contiguous(), A.val[keep].contiguous())
+        del keep, row_idx
+        moved = int(sel_e.sum().item())
+        self.share = moved / max(nnz, 1)
+        # the selected tiles' union lists, compacted
+        usz_s = torch.where(ok_t, usz, torch.zeros_like(usz))
+        first = torch.cumsum(usz_s, 0) - usz_s
+        cpos = torch.cumsum(sel_u.long(), 0) - 1
+        self.ucol = (ukey % m)[sel_u].int().contiguous() if moved else torch.zeros(1, dtype=torch.int32, device=dev)
+        nu = int(usz_s.sum().item())
+        self.nu = nu
+        self.union_ratio = nu / max(moved, 1)
+        e_tile = tile[sel_e]
+        e_uslot = cpos[inv[sel_e]] - first[e_tile]
+        e_i = rnk[sel_e] % R
+        e_val = A.val[sel_e]
+        del ukey, inv, utile, sel_u, cpos, tile, rnk, col, sel_e
+        # strip width of every tile: the widest of 64 / 32 / 16 / 8 that keeps a wave's share of a strip near one line
+        per_col = ssz.double() / usz.clamp(min=1).double() / NW                 # entries per wave and union column
+        w_t = torch.full((ntile,), WMAX, **i64)
+        for w in (WMAX // 2, WMAX // 4, WMAX // 8):
+            w_t = torch.where(per_col * (2 * w) > float(block_target), torch.full_like(w_t, w), w_t)
+        w_e = w_t[e_tile]
+        e_strip, e_slot = e_uslot // w_e, e_uslot % w_e
+        e_wave, e_rsub = e_i % NW, e_i // NW
+        del e_uslot, e_i, w_e
+        # strips and pieces of every tile
+        nstrip_t = (usz_s + w_t - 1) // w_t
+        np_t = (nstrip_t + self.piece_strips - 1) // self.piece_strips
+        spp_t = torch.where(np_t > 0, (nstrip_t + np_t.clamp(min=1) - 1) // np_t.clamp(min=1), torch.zeros_like(np_t))
+        np_t = torch.where(spp_t > 0, (nstrip_t + spp_t.clamp(min=1) - 1) // spp_t.clamp(min=1), torch.zeros_like(np_t))
+        sbase_t = torch.cumsum(nstrip_t, 0) - nstrip_t
+        pbase_t = torch.cumsum(np_t, 0) - np_t
+        npiece = int(np_t.sum().item())
+        nstrips = int(nstrip_t.sum().item())
+        ptile = torch.repeat_interleave(torch.arange(ntile, **i64), np_t)
+        pq = torch.arange(npiece, **i64) - pbase_t[ptile]
+        ps0 = pq * spp_t[ptile]
+        pnsp = torch.minimum(spp_t[ptile], nstrip_t[ptile] - ps0)
+        pk0 = first[ptile] + ps0 * w_t[ptile]
+        pk1 = torch.minimum(pk0 + pnsp * w_t[ptile], first[ptile] + usz_s[ptile])
+        psb = sbase_t[ptile] + ps0
+        cut_t = np_t > 1
+        part_t = torch.where(cut_t, np_t * R, torch.zeros_like(np_t))
+        tpart = torch.cumsum(part_t, 0) - part_t
+        pout = torch.where(cut_t[ptile], tpart[ptile] + pq * R, torch.full_like(pq, -1))
+        self.npartial = int(part_t.sum().item())
+        # entry blocks: (piece, wave, strip), contiguous per (piece, wave); inside a block by row, then column; a block is
+        # a whole number of lines (at least one: an empty block still tells the wave to move on to the next strip)
+        nblocks = nstrips * NW
+        if moved:
+            e_p = pbase_t[e_tile] + e_strip // spp_t[e_tile].clamp(min=1)
+            bidx = psb[e_p] * NW + e_wave * pnsp[e_p] + (e_strip - ps0[e_p])
+            del e_p, e_strip, e_wave, e_tile
+            perm = torch.argsort((bidx * RW + e_rsub) * WMAX + e_slot)
+            bcnt = torch.bincount(bidx, minlength=nblocks)
+            bfirst = torch.cumsum(bcnt, 0) - bcnt
+            sb = bidx[perm]
+            rank_in = torch.arange(moved, **i64) - bfirst[sb]
+        else:
+            bcnt = torch.zeros(nblocks, **i64)
+        nl = torch.clamp((bcnt + LINE - 1) // LINE, min=1)
+        lstart = torch.cumsum(nl, 0) - nl
+        nline = int(nl.sum().item()) if nblocks else 0
+        ent = torch.empty((nline + 4) * LINE, 2, dtype=torch.int32, device=dev)  # (+ slack: the kernel requests two lines ahead)
+        ent[:, 0] = WMAX << 11                                    # pad entries: the all-zero slice ...
+        ent[:, 1] = -2147483648                                   # ... times -0.0: fma(-0.0, +0.0, acc) == acc for every acc
+        if moved:
+            pos = lstart[sb] * LINE + rank_in
+            ent[pos, 0] = ((e_slot[perm] << 11) | (e_rsub[perm] * 4)).int()
+            ent[pos, 1] = e_val[perm].view(torch.int32)
+            del perm, bfirst, sb, pos, bidx, e_slot, e_rsub, e_val, rank_in
+        if nline:
+            lblk = torch.repeat_interleave(torch.arange(nblocks, **i64), nl)
+            l_in = torch.arange(nline, **i64) - lstart[lblk]
+            rem = torch.clamp(bcnt[lblk] - LINE * l_in, min=0, max=LINE)
+            ng = torch.clamp((rem + 3) // 4, min=1)
+            hdr = (ng << 20) | ((l_in == nl[lblk] - 1).long() << 24)
+            ent[torch.arange(nline, **i64) * LINE, 0] |= hdr.int()
+            del lblk, l_in, rem, ng, hdr
+        self.ent = ent
+        self.nline = nline
+        self.padding = nline * LINE / max(moved, 1)
+        ebase = lstart[(psb * NW)[:, None] + torch.arange(NW, **i64)[None, :] * pnsp[:, None]] if npiece else torch.zeros(0, NW, **i64)
+        rows = torch.full((ntile * R,), -1, **i64)
+        rows[:n] = order
+        self.rows = rows.int().contiguous()
+        # pieces in working order: most lines first
+        if npiece:
+            plines = torch.zeros(npiece, **i64)
+            strip_lines = nl.view(-1)                              # per block; sum over a piece's blocks
+            pid_of_block = torch.repeat_interleave(torch.arange(npiece, **i64), pnsp * NW)
+            # blocks are numbered piece after piece only if pieces are in tile order, which they are (psb ascends with the piece id)
+            plines.index_add_(0, pid_of_block, strip_lines)
+            o = torch.argsort(plines, descending=True, stable=True)
+        else:
+            o = torch.zeros(0, **i64)
+        zero = torch.zeros_like(pq)
+        self.desc = torch.stack([ptile, pk0, pk1, pout, pnsp, w_t[ptile], zero, zero], dim=1)[o].int().contiguous()
+        self.ebase = ebase[o].contiguous()
+        self.npiece, self.ntile = npiece, ntile
+        # cut list: one entry per (cut tile, member row): {row, first partial row, pieces, R - 1}
+        ct = torch.nonzero(cut_t).flatten()
+        crow = rows.view(ntile, R)[ct]
+        cbase = tpart[ct][:, None] + torch.arange(R, **i64)[None, :]
+        ccnt = np_t[ct][:, None].expand(-1, R)
+        okc = crow >= 0
+        self.cut = torch.stack([crow[okc], cbase[okc], ccnt[okc], torch.full_like(crow[okc], R - 1)], dim=1).int().contiguous()
+        self.ncut = int(self.cut.size(0))
+        in_tile = torch.zeros(ntile * R, dtype=torch.bool, device=dev)
+        in_tile.view(ntile, R)[ok_t] = True
+        self._strip_rows = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._strip_rows[order] = in_tile[:n]
+        self._cut_rows = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._cut_rows[crow[okc]] = True
+        self.tiles = int(ok_t.sum().item())
+        self.nbytes = 4 * (self.desc.numel() + self.rows.numel() + self.ucol.numel() + self.ent.numel()
+                           + 2 * self.ebase.numel() + self.cut.numel())
+        self.c = _CStripPlan(R, WMAX, NW, LINE, ntile, npiece, self.ncut, 0, self.desc.data_ptr(), self.rows.data_ptr(),
+                             self.ucol.data_ptr(), self.ent.data_ptr(), self.ebase.data_ptr(), self.cut.data_ptr(), nu, nline,
+                             self.npartial)
+        self._partial = {}
+
+    partial = SegPlan.partial
+
+    def strip_rows(self):
+        """Rows whose entries all run through the strip kernel (the others are whole in ``self.rest``)."""
+        return self._strip_rows
+
+    def cut_rows(self):
+        """Rows of tiles whose union list is cut into pieces (fixed-order piece sums instead of one chain)."""
+        return self._cut_rows
+
+
+class StripHybridPlan:
+    """A block as row strips + the rest: ``rest_plan`` (a plan of ``strip.rest``) runs first, with the call's beta /
+    overwrite (it lists every row); ``dgnn_spmm_strip_f32`` then adds the strip tiles. A row is whole in one of the two."""
+
+    def __init__(self, strip, rest_plan):
+        self.strip, self.rest_plan = strip, rest_plan
+
+    def uncut_rows(self):
+        """Rows whose result is one strict chain in ascending column order."""
+        return self.rest_plan.uncut_rows() & ~self.strip.cut_rows()
+
+    strict_rows = uncut_rows
+
+
+def spmm_strip(S, B, C, alpha=1.0):
+    """C += (strip tiles of S) @ B[:, :F]; B a padded feature block (pad_rows); alpha must be 1."""
+    bptr, ldb = _dense(B, 'B')
+    cptr, ldc = _dense(C, 'C')
+    F = C.size(1)
+    dev = C.device
+    P = S.partial(ldb, dev)
+    args = (ctypes.byref(S.c), S.rest.n, S.rest.m, bptr, ldb, cptr, ldc, P.data_ptr(), ldb, F, float(alpha))
+    if torch.cuda.current_device() == dev.index:
+        rc = _lib.dgnn_spmm_strip_f32(*args, _stream(C))
+    else:
+        with torch.cuda.device(dev):
+            rc = _lib.dgnn_spmm_strip_f32(*args, _stream(C))
+    _check(rc, 'spmm_strip')
+
+
+def _strip_for(A):
+    """The StripPlan of a block if row strips pay for it, else None (decided once per block). DGNN_STRIP=0 never,
+    DGNN_STRIP=1 whenever any tile qualifies, default: blocks with at least 32 nonzeros per row and 4 M nonzeros whose
+    selected tiles take at least a third of the nonzeros."""
+    want = os.environ.get('DGNN_STRIP', 'auto')
+    min_nnz = int(os.environ.get('DGNN_STRIP_MIN_NNZ', 1 << 22))
+    min_deg = float(os.environ.get('DGNN_STRIP_MIN_DEG', 32))
+    if want == '0' or A.nnz < max(min_nnz, 1) or float(A.nnz) / max(A.n, 1) < min_deg:
+        return None
+    if '_strip_plan' not in A.__dict__:
+        S = StripPlan(A)
+        if S.npiece == 0 or (want != '1' and S.share < 1.0 / 3):
+            S = None
+        A.__dict__['_strip_plan'] = S
+    return A.__dict__['_strip_plan']
 
 
 def _dense_for(A):

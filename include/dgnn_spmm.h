@@ -274,6 +274,57 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
                         int32_t F, float alpha, void* stream);
 
 /*
+ * Row strips: tiles of 256 rows (ranked by length, so that a tile's rows share the hub columns) whose union column list
+ * is streamed ONCE through LDS in strips of 64 columns (LDS-DMA, double-buffered) -- "feature tiles of H_j staged in
+ * LDS" (north_star). Each of the workgroup's 16 waves keeps 16 rows' accumulators for a 256-float feature chunk in
+ * registers and walks a flat list of its (slot, row, value) entries per strip; the accumulator row is selected by VGPR
+ * index mode, the B operand comes from LDS (two ds_read_b64 per entry and wave), so the address unit sees one 1-KiB slice
+ * per (tile, column) instead of one per nonzero (Reddit shape: 0.15 of the nonzeros). The host-side builder
+ * (spmm_cpp.StripPlan) takes the tiles whose union is short enough out of the CSR block -- the rest goes through
+ * dgnn_spmm_plan_f32 first -- and this call ADDS the strip part:  C += A_strip * B  (alpha must be 1).
+ *   rows_per_tile 256, strip_cols 64 (the widest strip), waves 16, line_entries 32 (the kernel's geometry; anything else
+ *           is DGNN_E_BADARG)
+ *   rows    device, int32[256 * ntile]: member i of tile t (-1 = none); wave w owns members w, w + 16, w + 32, ...
+ *   ucol    device, int32[nu]: union columns, tile after tile, ascending inside a tile
+ *   desc    device, int32[8 * npiece]: {tile, k0, k1, out, strips, columns per strip (8, 16, 32 or 64), 0, 0} per piece
+ *           = consecutive strips of union entries [k0, k1) of one tile, in working order; out < 0: the members accumulate
+ *           into C, else the piece sums go to partial rows out + i and are merged per row (cut list {row, first partial
+ *           row, pieces, 255}, as in dgnn_plan)
+ *   ebase   device, int64[16 * npiece]: first line of (piece, wave)'s entry stream
+ *   ent     device, 256-byte aligned, uint32[64 * nline (+ 256 of slack)]: lines of 32 entries {slot << 11 | member
+ *           row / 16 * 4, value bits}; the entries of (piece, wave, strip) are a block of whole lines, blocks in strip
+ *           order; a line's first entry also carries, in bits 20-23, the groups of 4 entries to take from the line (1..8)
+ *           and, in bit 24, "last line of its block"; pad entries {64 << 11, 0x80000000 (-0.0)}
+ *   npartial  rows the partial buffer must hold
+ * Every row sums its own nonzeros in ascending column order starting from what C holds, one fused multiply-add each:
+ * rows of uncut tiles carry the bits of dgnn_spmm_csr_f32; rows of cut tiles the fixed-order piece sums. Pad entries
+ * change nothing (fma(-0.0, +0.0, acc) == acc for every acc). No MFMA, no atomics. No counterpart in the reference
+ * (spmm.cpp:26-28 is the operation).
+ */
+typedef struct dgnn_strip_plan {
+  int32_t rows_per_tile;
+  int32_t strip_cols;
+  int32_t waves;
+  int32_t line_entries;
+  int32_t ntile;
+  int32_t npiece;
+  int32_t ncut;
+  int32_t reserved;
+  const int32_t* desc;
+  const int32_t* rows;
+  const int32_t* ucol;
+  const uint32_t* ent;
+  const int64_t* ebase;
+  const int32_t* cut;
+  int64_t nu;
+  int64_t nline;
+  int64_t npartial;
+} dgnn_strip_plan;
+int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                        int32_t F, float alpha, void* stream);
+
+/*
  * spmm_cusparse's operand list (row-sorted COO, spmm.cpp:16-17) on the fast kernel, for callers that hand
  * over a fresh COO every call as the reference's models do (gcn.py:11) and so cannot keep a plan: a
  * work plan is built on the stream, on the device (column-block stages; per stage the runs grouped by

@@ -958,63 +958,24 @@ constexpr int STRIP_LDS = STRIP_LDS_B + STRIP_NW * STRIP_RING * STRIP_LINE * 8;
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// one group of 4 entries: entry k of the line sits in lanes 2k (slot << 11 | row * 4 [| header]) and 2k + 1 (value) of v28
-#define STRIP_RL(S, L) "v_readlane_b32 s" #S ", v28, " #L "\n\t"
-#define STRIP_FMA(S0, S1, VLO0, VLO1, VHI0, VHI1)                                                                    \
-  "v_pk_fma_f32 v[64:65], s[" #S0 ":" #S1 "], v[" #VLO0 ":" #VLO1 "], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
-  "v_pk_fma_f32 v[66:67], s[" #S0 ":" #S1 "], v[" #VHI0 ":" #VHI1 "], v[66:67] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-#define STRIP_GROUP_HEAD(L0, L1, L2, L3, L4, L5, L6, L7)                                                             \
-  STRIP_RL(36, L0) STRIP_RL(37, L1) STRIP_RL(38, L2) STRIP_RL(39, L3)                                                \
-  STRIP_RL(40, L4) STRIP_RL(41, L5) STRIP_RL(42, L6) STRIP_RL(43, L7)
-#define STRIP_GROUP_BODY(NEXT)                                                                                       \
-  "v_and_or_b32 v24, s36, %[mask], %[lb]\n\t"                                                                        \
-  "v_and_or_b32 v25, s38, %[mask], %[lb]\n\t"                                                                        \
-  "v_and_or_b32 v26, s40, %[mask], %[lb]\n\t"                                                                        \
-  "v_and_or_b32 v27, s42, %[mask], %[lb]\n\t"                                                                        \
-  "ds_read_b64 v[32:33], v24\n\t"                                                                                    \
-  "ds_read_b64 v[34:35], v24 offset:512\n\t"                                                                         \
-  "ds_read_b64 v[36:37], v25\n\t"                                                                                    \
-  "ds_read_b64 v[38:39], v25 offset:512\n\t"                                                                         \
-  "ds_read_b64 v[40:41], v26\n\t"                                                                                    \
-  "ds_read_b64 v[42:43], v26 offset:512\n\t"                                                                         \
-  "ds_read_b64 v[44:45], v27\n\t"                                                                                    \
-  "ds_read_b64 v[46:47], v27 offset:512\n\t"                                                                         \
-  "s_set_gpr_idx_on s36, 0xc\n\t"                                                                                    \
-  "s_waitcnt lgkmcnt(6)\n\t" STRIP_FMA(36, 37, 32, 33, 34, 35)                                                       \
-  "s_set_gpr_idx_idx s38\n\t"                                                                                        \
-  "s_waitcnt lgkmcnt(4)\n\t" STRIP_FMA(38, 39, 36, 37, 38, 39)                                                       \
-  "s_set_gpr_idx_idx s40\n\t"                                                                                        \
-  "s_waitcnt lgkmcnt(2)\n\t" STRIP_FMA(40, 41, 40, 41, 42, 43)                                                       \
-  "s_set_gpr_idx_idx s42\n\t"                                                                                        \
-  "s_waitcnt lgkmcnt(0)\n\t" STRIP_FMA(42, 43, 44, 45, 46, 47)                                                       \
-  "s_set_gpr_idx_off\n\t"                                                                                            \
-  "s_cmp_eq_u32 s44, " #NEXT "\n\t"                                                                                  \
-  "s_cbranch_scc1 9f\n\t"
-
-// Multiply the line at LDS address `ra` (lane l: dword l of the line) into the accumulators. The line's first entry
-// carries the header: bits 20-23 the groups of 4 entries to take (1..8), bit 24 "last line of this strip". Returns bit 24.
-__device__ __forceinline__ uint32_t strip_line(f32x32& accA, f32x32& accB, uint32_t ra, uint32_t lb) {
+// Multiply the line at LDS address `ra` (lane l: dword l of the line) into the accumulators. The instruction stream comes from
+// tools/gen_strip_asm.py (groups of 4 entries, software-pipelined across two register sets): entry k of the line sits in
+// lanes 2k (slot << 11 | row * 4 [| header]) and 2k + 1 (value) of v28; v_readlane_b32 broadcasts it into an SGPR pair that
+// is the first operand of the packed FMAs as it stands (op_sel picks the value for both halves) and whose low byte is the
+// accumulator index; (pair.x & mask) | lane base is the LDS address of the column's slice. The line's first entry
+// carries the header: bits 20-23 the groups of 4 entries to take (1..8), bit 24 "last line of this strip". Returns bit 24;
+// k0..k3 = dwords 60..63 of the line (the first line of a block keeps column ids there, and at most 7 groups of entries).
+__device__ __forceinline__ uint32_t strip_line(f32x32& accA, f32x32& accB, uint32_t ra, uint32_t lb,
+                                               int& k0, int& k1, int& k2, int& k3) {
   const uint32_t mask = 0x0003fe00u;
   uint32_t last;
   asm volatile(
-      "ds_read_b32 v28, %[ra]\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      STRIP_GROUP_HEAD(0, 1, 2, 3, 4, 5, 6, 7)
-      "s_bfe_u32 s44, s36, 0x40014\n\t"                        // groups in this line
-      "s_bfe_u32 %[last], s36, 0x10018\n\t"
-      STRIP_GROUP_BODY(1)
-      STRIP_GROUP_HEAD(8, 9, 10, 11, 12, 13, 14, 15) STRIP_GROUP_BODY(2)
-      STRIP_GROUP_HEAD(16, 17, 18, 19, 20, 21, 22, 23) STRIP_GROUP_BODY(3)
-      STRIP_GROUP_HEAD(24, 25, 26, 27, 28, 29, 30, 31) STRIP_GROUP_BODY(4)
-      STRIP_GROUP_HEAD(32, 33, 34, 35, 36, 37, 38, 39) STRIP_GROUP_BODY(5)
-      STRIP_GROUP_HEAD(40, 41, 42, 43, 44, 45, 46, 47) STRIP_GROUP_BODY(6)
-      STRIP_GROUP_HEAD(48, 49, 50, 51, 52, 53, 54, 55) STRIP_GROUP_BODY(7)
-      STRIP_GROUP_HEAD(56, 57, 58, 59, 60, 61, 62, 63) STRIP_GROUP_BODY(8)
-      "9:\n\t"
-      : "+{v[64:95]}"(accA), "+{v[96:127]}"(accB), [last] "=&s"(last)
+#include "strip_line_asm.inc"
+      : "+{v[64:95]}"(accA), "+{v[96:127]}"(accB), [last] "=&s"(last), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
       : [ra] "v"(ra), [mask] "v"(mask), [lb] "v"(lb)
       : "v24", "v25", "v26", "v27", "v28", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",
-        "v44", "v45", "v46", "v47", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "scc", "memory");
+        "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+        "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "scc", "memory");
   return last;
 }
 
@@ -1064,7 +1025,7 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
   // so the requests simply walk it; what a line holds is in its header. Column ids come through the scalar cache
   // (wave-uniform, requested a strip ahead).
   const char* const Bb = reinterpret_cast<const char*>(B) + (int64_t)chunk * (STRIP_CH * 4) + lane * 16;
-  const bool dma = chunk * STRIP_CH + lane * 4 < (int)ldb && !(dbg & 2);     // lanes past the padded width move nothing
+  const bool dma = chunk * STRIP_CH + lane * 4 < (int)ldb && !(dbg & 2);     // lanes past the padded width move nothing (dbg: timing experiments)
   const uint64_t ldb_bytes = (uint64_t)ldb * 4u;
   const int wslot = wave * 4;                                  // wave w moves slots 4 w .. 4 w + 3 of a strip
   const int kw = k0 + wslot;
@@ -1087,10 +1048,10 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
   const uint32_t* lp = ent + ebase[(int64_t)piece * STRIP_NW + wave] * (STRIP_LINE * 2) + lane;   // next line to request, this lane's dword
   unsigned char* const ring = lds + STRIP_LDS_B + wave * (STRIP_RING * STRIP_LINE * 8);
   const uint32_t ring_ra = (uint32_t)(STRIP_LDS_B + wave * (STRIP_RING * STRIP_LINE * 8) + lane * 4);
-  int c0, c1, c2, c3;
+  int c0, c1, c2, c3;                                          // columns of the wave's four slots of the next strip to fill
   STRIP_COLS(0, c0, c1, c2, c3)
   STRIP_FILL(0, c0, c1, c2, c3)
-  STRIP_COLS(1, c0, c1, c2, c3)
+  STRIP_COLS(1, c0, c1, c2, c3)                                // (the only scalar loads: later ids ride in the entry lines)
   __builtin_amdgcn_global_load_lds((const void*)lp, (lds_void_ptr)(ring), 4, 0, 0);
   lp += STRIP_LINE * 2;
   __builtin_amdgcn_global_load_lds((const void*)lp, (lds_void_ptr)(ring + STRIP_LINE * 8), 4, 0, 0);
@@ -1104,19 +1065,15 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
     if (first) {
       __builtin_amdgcn_s_barrier();                             // everybody's slices of s are in; everybody is done with s - 1
       if (s + 1 < nsp) STRIP_FILL(s + 1, c0, c1, c2, c3)
-      STRIP_COLS(s + 2, c0, c1, c2, c3)
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_global_load_lds((const void*)lp, (lds_void_ptr)(ring + ws * (STRIP_LINE * 8)), 4, 0, 0);
     lp += STRIP_LINE * 2;
     ws = ws == STRIP_RING - 1 ? 0 : ws + 1;
     const uint32_t lb = (uint32_t)lane * 8u + (uint32_t)(s & 1) * 1024u;
-    uint32_t last = 1;
-    if (!(dbg & 1)) last = strip_line(accA, accB, ring_ra + rs * (STRIP_LINE * 8), lb);
-    else {                                                      // (timing experiments: read the header only)
-      const uint32_t h = *reinterpret_cast<const volatile uint32_t*>(ring + rs * (STRIP_LINE * 8));
-      last = (__builtin_amdgcn_readfirstlane(h) >> 24) & 1u;
-    }
+    int n0, n1, n2, n3;
+    const uint32_t last = strip_line(accA, accB, ring_ra + rs * (STRIP_LINE * 8), lb, n0, n1, n2, n3);
+    if (first) { c0 = n0; c1 = n1; c2 = n2; c3 = n3; }          // a block's first line names the columns of strip s + 2
     rs = rs == STRIP_RING - 1 ? 0 : rs + 1;
     first = last;
     s += (int)last;
@@ -1967,7 +1924,7 @@ int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
     ProfScope prof(s, 0);
     hipLaunchKernelGGL(spmm_strip_kernel, dim3((unsigned)nitems), dim3(STRIP_NW * 64), 0, s, plan->desc, plan->npiece, plan->rows,
                        plan->ucol, plan->ent, plan->ebase, B, ldb, C, ldc, partial, ldp, F, vw2,
-                       g_variant >= 500 && g_variant < 504 ? g_variant - 500 : 0);
+                       g_variant == 502 ? 2 : 0);
     DGNN_HIP(hipGetLastError());
   }
   if (plan->ncut > 0) {

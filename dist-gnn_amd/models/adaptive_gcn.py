@@ -32,6 +32,7 @@ class AdaptiveState:
         self.cur_epoch, self.warm_epoch, self.epsilon, self.enabled = 0, warm_epoch, epsilon, enabled
         self.cache = {'layer1': {}, 'layer2': {}}
         self.decisions = []            # (epoch, btype, [use_cache per src]) log for tests / tracing
+        self.trace = None              # a list here collects (epoch, btype, aggregation result) of every pass (tests)
 
 
 state = AdaptiveState()
@@ -53,8 +54,8 @@ class _Policy:
 def adaptive_broadcast(adj_parts, feature, btype):
     env = DistEnv.env
     P, rank = env.world_size, env.rank
-    if not state.enabled or btype not in state.cache:
-        return _gcn.pipeline().run(adj_parts, feature, btype, policy=_gcn_nocache())
+    if not state.enabled or btype not in state.cache:       # 'layer3' and every backward pass: always sent (dist_1d.py:139-140)
+        return _traced(btype, _gcn.pipeline().run(adj_parts, feature, btype, policy=_gcn_nocache()))
     have_all = all(src in state.cache[btype] for src in range(P))
     if btype == 'layer1':
         use = [state.cur_epoch >= 1 and have_all] * P
@@ -68,7 +69,13 @@ def adaptive_broadcast(adj_parts, feature, btype):
         dist.all_gather(gathered, flags, group=env.world_group)
         use = [bool(f.item()) and src in state.cache[btype] for src, f in enumerate(gathered)]
     state.decisions.append((state.cur_epoch, btype, list(use)))
-    return _gcn.pipeline().run(adj_parts, feature, btype, policy=_Policy(btype, use, rank, feature))
+    return _traced(btype, _gcn.pipeline().run(adj_parts, feature, btype, policy=_Policy(btype, use, rank, feature)))
+
+
+def _traced(btype, z):
+    if state.trace is not None:
+        state.trace.append((state.cur_epoch, btype, z.detach().clone()))
+    return z
 
 
 def _gcn_nocache():
@@ -87,21 +94,30 @@ AdaptiveGCNLayer = _gcn.aggregation_layer('AdaptiveGCNLayer', adaptive_broadcast
 
 
 class AdaptiveGCN(nn.Module):
-    """2-layer GCN of dist_1d.py:206-208 (ReLU, then log_softmax; train with nll_loss). Call
-    ``set_epoch(e)`` before each epoch: the policy is a function of the epoch number."""
+    """2-layer GCN of dist_1d.py:206-208 (ReLU, then log_softmax; train with nll_loss), or with ``num_layers=3`` the
+    model of dist_1d_4layers.py:207-211 (ReLU, ReLU, log_softmax; its third aggregation, 'layer3', always travels, and
+    its epsilon is 0.10, :73). Call ``set_epoch(e)`` before each epoch: the policy is a function of the epoch number."""
 
-    def __init__(self, g, env, hidden_dim=16, warm_epoch=50, epsilon=0.040):
+    def __init__(self, g, env, hidden_dim=16, warm_epoch=50, epsilon=None, num_layers=2):
         super().__init__()
-        self.g, self.env = g, env
+        if num_layers not in (2, 3):
+            raise ValueError('AdaptiveGCN: 2 layers (dist_1d.py) or 3 (dist_1d_4layers.py)')
+        self.g, self.env, self.num_layers = g, env, num_layers
+        if epsilon is None:
+            epsilon = 0.040 if num_layers == 2 else 0.10
         state.__init__(warm_epoch, epsilon, True)
+        dims = [g.features.size(1)] + [hidden_dim] * (num_layers - 1) + [g.num_classes]
         torch.manual_seed(0)
-        self.weight1 = nn.Parameter(torch.rand(g.features.size(1), hidden_dim).to(env.device))
-        self.weight2 = nn.Parameter(torch.rand(hidden_dim, g.num_classes).to(env.device))
+        for i in range(num_layers):
+            setattr(self, f'weight{i + 1}', nn.Parameter(torch.rand(dims[i], dims[i + 1]).to(env.device)))
 
     @staticmethod
     def set_epoch(epoch):
         state.cur_epoch = epoch
 
     def forward(self, features):
-        h = F.relu(AdaptiveGCNLayer.apply(features, self.weight1, self.g.adj_parts, 'layer1'))
-        return F.log_softmax(AdaptiveGCNLayer.apply(h, self.weight2, self.g.adj_parts, 'layer2'), dim=1)
+        h = features
+        for i in range(self.num_layers):
+            h = AdaptiveGCNLayer.apply(h, getattr(self, f'weight{i + 1}'), self.g.adj_parts, f'layer{i + 1}')
+            h = F.relu(h) if i + 1 < self.num_layers else F.log_softmax(h, dim=1)
+        return h

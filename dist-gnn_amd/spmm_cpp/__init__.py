@@ -1164,25 +1164,39 @@ class StripPlan:
             rank_in = torch.arange(moved, **i64) - bfirst[sb]
         else:
             bcnt = torch.zeros(nblocks, **i64)
-        nl = torch.clamp((bcnt + LINE - 1) // LINE, min=1)
+        FIRST = LINE - 4                                           # a block's first line: 28 entries + 4 column ids
+        nl = 1 + torch.clamp(bcnt - FIRST + LINE - 1, min=0) // LINE
         lstart = torch.cumsum(nl, 0) - nl
         nline = int(nl.sum().item()) if nblocks else 0
         ent = torch.empty((nline + 4) * LINE, 2, dtype=torch.int32, device=dev)  # (+ slack: the kernel requests two lines ahead)
         ent[:, 0] = WMAX << 11                                    # pad entries: the all-zero slice ...
         ent[:, 1] = -2147483648                                   # ... times -0.0: fma(-0.0, +0.0, acc) == acc for every acc
         if moved:
-            pos = lstart[sb] * LINE + rank_in
+            later = torch.clamp(rank_in - FIRST, min=0)
+            pos = torch.where(rank_in < FIRST, lstart[sb] * LINE + rank_in, (lstart[sb] + 1 + later // LINE) * LINE + later % LINE)
             ent[pos, 0] = ((e_slot[perm] << 11) | (e_rsub[perm] * 4)).int()
             ent[pos, 1] = e_val[perm].view(torch.int32)
-            del perm, bfirst, sb, pos, bidx, e_slot, e_rsub, e_val, rank_in
+            del perm, bfirst, sb, pos, bidx, e_slot, e_rsub, e_val, rank_in, later
         if nline:
             lblk = torch.repeat_interleave(torch.arange(nblocks, **i64), nl)
             l_in = torch.arange(nline, **i64) - lstart[lblk]
-            rem = torch.clamp(bcnt[lblk] - LINE * l_in, min=0, max=LINE)
+            rem = torch.where(l_in == 0, torch.clamp(bcnt[lblk], max=FIRST),
+                              torch.clamp(bcnt[lblk] - FIRST - LINE * (l_in - 1), min=0, max=LINE))
             ng = torch.clamp((rem + 3) // 4, min=1)
             hdr = (ng << 20) | ((l_in == nl[lblk] - 1).long() << 24)
             ent[torch.arange(nline, **i64) * LINE, 0] |= hdr.int()
             del lblk, l_in, rem, ng, hdr
+            # the first line of the block of (piece, wave w, strip sp) names the columns of slots 4 w .. 4 w + 3 of strip sp + 2
+            bp = torch.repeat_interleave(torch.arange(npiece, **i64), pnsp * NW)      # blocks are numbered piece after piece
+            within = torch.arange(nblocks, **i64) - (psb * NW)[bp]
+            bw, bsp = within // pnsp[bp], within % pnsp[bp]
+            kk = pk0[bp][:, None] + ((bsp + 2) * w_t[ptile][bp] + bw * 4)[:, None] + torch.arange(4, **i64)[None, :]
+            kk = torch.minimum(torch.maximum(kk, pk0[bp][:, None]), (pk1[bp] - 1)[:, None])
+            ids = self.ucol[kk.view(-1)].view(-1, 4)
+            flat = ent.view(-1)
+            at = (lstart * (2 * LINE) + 2 * LINE - 4)[:, None] + torch.arange(4, **i64)[None, :]
+            flat[at.view(-1)] = ids.view(-1)
+            del bp, within, bw, bsp, kk, ids, at
         self.ent = ent
         self.nline = nline
         self.padding = nline * LINE / max(moved, 1)

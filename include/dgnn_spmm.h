@@ -294,7 +294,9 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
  *   ent     device, 256-byte aligned, uint32[64 * nline (+ 256 of slack)]: lines of 32 entries {slot << 11 | member
  *           row / 16 * 4, value bits}; the entries of (piece, wave, strip) are a block of whole lines, blocks in strip
  *           order; a line's first entry also carries, in bits 20-23, the groups of 4 entries to take from the line (1..8)
- *           and, in bit 24, "last line of its block"; pad entries {64 << 11, 0x80000000 (-0.0)}
+ *           and, in bit 24, "last line of its block"; the FIRST line of the block of strip s holds at most 28 entries and,
+ *           in its last four dwords, the columns of the wave's slots 4 w .. 4 w + 3 of strip s + 2 (clamped into
+ *           [k0, k1 - 1]); pad entries {64 << 11, 0x80000000 (-0.0)}
  *   npartial  rows the partial buffer must hold
  * Every row sums its own nonzeros in ascending column order starting from what C holds, one fused multiply-add each:
  * rows of uncut tiles carry the bits of dgnn_spmm_csr_f32; rows of cut tiles the fixed-order piece sums. Pad entries

@@ -192,3 +192,98 @@ def layer_backward(adj_parts, grad_out_blocks, features_local, W):
     NB the same (un-transposed) blocks are used, exactly like gcn.py:47."""
     ag = broadcast_aggregate(adj_parts, grad_out_blocks)
     return ag @ W.T, features_local.T @ ag
+
+
+# --------------------------------------------------------------------------- adaptive broadcast (older trainer)
+def _log_softmax(x):
+    m = x.max(axis=1, keepdims=True)
+    e = x - m
+    return (e - np.log(np.exp(e).sum(axis=1, keepdims=True, dtype=np.float32))).astype(np.float32)
+
+
+def adaptive_reference(adj_parts_by_rank, features_by_rank, labels_by_rank, train_mask_by_rank, weights, epochs,
+                       warm_epoch=50, epsilon=0.040, lr=0.01):
+    """1D_CAGNET/dist_1d.py:59-158 (broad_func with its caches), :161-203 (GCNFunc), :206-222 (train) and :244-262
+    (Adam, lr 0.01, weights from one seed on every rank), all P ranks simulated in lockstep in one process; with three
+    weights the model of dist_1d_4layers.py:207-211 (ReLU, ReLU, log_softmax; epsilon 0.10 there, :73).
+
+    Per broadcast type (dist_1d.py:67-142): 'layer1' blocks travel in epoch 0 and are reused afterwards (:68, :96-102);
+    'layer2': the OWNER of a block compares it with the copy it last sent (F.l1_loss = mean absolute difference,
+    :107-109) and reuses that copy iff cur_epoch >= warm_epoch and diff < epsilon (:109), telling the others with a
+    one-float broadcast (:111-114); when a block is reused every rank but the owner multiplies its stored copy, the owner
+    its current block (:98-99, :118-119); every other pass ('layer3', the backward passes) always travels (:77-81,
+    :139-140). The aggregation multiplies the SAME blocks forward and backward (:190), grad_weight is summed over the
+    ranks (:27).
+
+    adj_parts_by_rank[r][i] = (row, col, val, shape) of A[r, i]; returns a list over epochs of dicts with
+    'z' (per layer, per rank: the aggregations), 'use2' (per source: was the stored copy used), 'diff2' (per source:
+    the owner's mean absolute difference, None before anything was sent), 'loss' (per rank; None where a rank has no
+    training node)."""
+    P = len(features_by_rank)
+    Ws = [_f32c(W).copy() for W in weights]
+    L = len(Ws)
+    adam = [dict(m=np.zeros_like(W), v=np.zeros_like(W)) for W in Ws]
+    b1, b2, eps_adam = 0.9, 0.999, 1e-8
+    sent2 = [None] * P                       # cache_layer2[i] on every rank = the block rank i last sent
+    out = []
+
+    def aggregate(r, blocks):
+        shape = adj_parts_by_rank[r][0][3]
+        z = np.zeros((shape[0], blocks[0].shape[1]), dtype=np.float32)
+        for i in range(P):
+            row, col, val, shape = adj_parts_by_rank[r][i]
+            spmm_coo(row, col, val, shape[0], shape[1], _f32c(blocks[i]), z, 1.0, 1.0)
+        return z
+
+    for epoch in range(epochs):
+        H = [[_f32c(f) for f in features_by_rank]]                      # H[l][r]: input of layer l + 1
+        zs, pres, use2, diff2 = [], [], [False] * P, [None] * P
+        for l in range(L):
+            cur = H[l]
+            if l == 1:                                                  # 'layer2': one decision per source, made by its owner
+                for i in range(P):
+                    if sent2[i] is not None:
+                        diff2[i] = float(np.abs(cur[i] - sent2[i]).mean(dtype=np.float32))
+                        use2[i] = bool(epoch >= warm_epoch and np.float32(diff2[i]) < np.float32(epsilon))
+                    else:
+                        use2[i] = bool(epoch >= warm_epoch and epoch % 5 > 0)      # (:75; never true in epoch 0)
+                z = [aggregate(r, [cur[i] if (i == r or not use2[i]) else sent2[i] for i in range(P)]) for r in range(P)]
+                for i in range(P):
+                    if not use2[i]:
+                        sent2[i] = cur[i].copy()
+            else:                                                       # 'layer1' (constant input: the copies ARE the blocks), 'layer3'
+                z = [aggregate(r, cur) for r in range(P)]
+            pre = [(z[r] @ Ws[l]).astype(np.float32) for r in range(P)]
+            zs.append(z)
+            pres.append(pre)
+            H.append([np.maximum(p, 0).astype(np.float32) for p in pre] if l + 1 < L else [_log_softmax(p) for p in pre])
+        logp = H[L]
+        # loss = nll_loss(mean over the rank's training rows) (:215); d loss / d O through log_softmax (:178-181)
+        G, losses = [], []
+        for r in range(P):
+            idx = np.nonzero(train_mask_by_rank[r])[0]
+            g = np.zeros_like(logp[r])
+            if idx.size:
+                y = labels_by_rank[r][idx].astype(np.int64)
+                losses.append(float(-logp[r][idx, y].mean(dtype=np.float32)))
+                sm = np.exp(logp[r][idx]).astype(np.float32)
+                sm[np.arange(idx.size), y] -= 1.0
+                g[idx] = sm / np.float32(idx.size)
+            else:
+                losses.append(None)                                     # fake loss: zero gradient (:218-220)
+            G.append(g.astype(np.float32))
+        grads = [None] * L
+        for l in range(L - 1, -1, -1):                                  # backward passes: always sent, same blocks (:190)
+            ag = [aggregate(r, G) for r in range(P)]
+            grads[l] = sum((H[l][r].T @ ag[r]).astype(np.float32) for r in range(P))
+            if l > 0:
+                G = [((ag[r] @ Ws[l].T).astype(np.float32) * (pres[l - 1][r] > 0)).astype(np.float32) for r in range(P)]
+        out.append(dict(z=zs, use2=use2, diff2=diff2, loss=losses))
+        for W, g, st in zip(Ws, grads, adam):                           # torch.optim.Adam defaults, lr 0.01 (:262)
+            t = epoch + 1
+            st['m'] = (b1 * st['m'] + (1 - b1) * g).astype(np.float32)
+            st['v'] = (b2 * st['v'] + (1 - b2) * g * g).astype(np.float32)
+            mhat = st['m'] / np.float32(1 - b1 ** t)
+            vhat = st['v'] / np.float32(1 - b2 ** t)
+            W -= (np.float32(lr) * mhat / (np.sqrt(vhat) + np.float32(eps_adam))).astype(np.float32)
+    return out

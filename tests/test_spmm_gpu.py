@@ -841,6 +841,101 @@ def test_dense_tiles_plus_remainder_match_the_oracle(n, m, nnz, hubs, F, min_cou
     assert torch.equal(view, Cg) and (wide[:, F:] == 7.0).all()
 
 
+@pytest.mark.parametrize('n,m,nnz,hubs,F,max_ratio,piece,block,beta', [
+    (3000, 5000, 250000, 3, 256, 0.9, 256, 26, 1.0), (2500, 4000, 200000, 2, 602, 0.9, 8, 26, 0.0),
+    (1501, 9000, 150000, 2, 128, 0.95, 3, 10, 2.0), (4003, 1200, 120000, 0, 100, 0.9, 256, 60, 1.0),
+    (700, 700, 60000, 4, 130, 1.0, 256, 26, 1.0), (2001, 3000, 160000, 2, 41, 0.9, 5, 26, 0.0),
+    (5000, 6000, 400000, 6, 300, 0.6, 16, 200, 1.0)])
+def test_row_strips_plus_rest_match_the_oracle(n, m, nnz, hubs, F, max_ratio, piece, block, beta):
+    """Row strips (dgnn_spmm_strip_f32, spmm_cpp.StripPlan / StripHybridPlan): tiles of 256 rows whose union column list
+    goes through LDS once, a flat entry list per wave multiplied in VGPR index mode; tiles with poor reuse stay with the
+    sparse plans. A row is whole in one of the two parts and sums its nonzeros in ascending column order, so EVERY row of
+    an uncut tile carries the oracle's bits -- hub rows whose blocks span several entry lines, strips of 8 to 64 columns,
+    widths that are no multiple of the 256-float chunk, rows with nothing; rows of cut tiles meet the fp64 bound; beta = 0
+    overwrites a NaN-filled C; pad entries change nothing; same bits from run to run."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(n + F + piece)
+    row, col, val = _rand_csr(rng, n, m, nnz, hub_rows=hubs)
+    fold = rng.random(col.size) < 0.6                                    # popular columns, so that rows share some
+    col = np.where(fold, col % 150, col).astype(np.int32)
+    key = np.unique(row.astype(np.int64) * m + col)
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    val = rng.random(key.size, dtype=np.float32) - 0.3
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    C0 = rng.standard_normal((n, F), dtype=np.float32)
+    if beta == 0.0:
+        C0[:] = np.nan
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, C0.copy(), 1.0, beta)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    S = spmm_cpp.StripPlan(blk, max_ratio, piece, min_tile_nnz=64, block_target=block)
+    assert S.npiece > 0 and 0 < S.share <= 1.0 and S.union_ratio <= max_ratio and S.rest.nnz == key.size - round(S.share * key.size)
+    widths = set(S.desc[:, 5].cpu().tolist())
+    assert widths <= {8, 16, 32, 64}
+    plan = spmm_cpp.StripHybridPlan(S, spmm_cpp.SegPlan(S.rest, 2))
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+    Cg = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, Cg, 1.0, beta, plan)
+    got = Cg.cpu().numpy()
+    assert np.isfinite(got).all()
+    rowptr = ref_cpu.coo2csr(row, n)
+    _check(got, want, rowptr, col, val, B, np.nan_to_num(C0), 1.0, beta)
+    uncut = plan.uncut_rows().cpu().numpy()
+    in_strips = S.strip_rows().cpu().numpy()
+    assert in_strips.sum() >= 256 and (piece < 64 or (uncut & in_strips).sum() >= 256)
+    assert np.array_equal(got[uncut], want[uncut])                        # the strict chain's bits, strip rows included
+    if piece < 64:
+        assert S.ncut > 0 and S.npartial > 0                              # (these cases cut tiles into pieces)
+    again = torch.from_numpy(C0).to(dev)
+    spmm_cpp.spmm_plan(blk, Bp, again, 1.0, beta, plan)
+    assert torch.equal(again, Cg)
+    if beta == 0.0:
+        over = torch.full((n, F), float('nan'), device=dev)
+        spmm_cpp.spmm_plan(blk, Bp, over, 1.0, 1.0, plan, overwrite=True)
+        assert torch.equal(over, Cg)
+    with pytest.raises(RuntimeError, match='alpha'):
+        spmm_cpp.spmm_plan(blk, Bp, Cg, 0.5, 1.0, plan)
+
+
+def test_row_strips_keep_non_finite_values_with_their_neighbours():
+    """A non-finite feature row reaches exactly the rows that reference it (the reference's SpMM, spmm.cpp:26-28, has no
+    other behaviour): the strip kernel's pad entries multiply an all-zero slice by -0.0 and add nothing, and no row is
+    given a zero weight for a column it does not own. Signed zeros survive too: a row of negative zeros stays negative."""
+    import spmm_cpp
+    rng = np.random.default_rng(77)
+    n = m = 1500
+    row, col, val = _rand_csr(rng, n, m, 120000, hub_rows=2)
+    col = np.where(rng.random(col.size) < 0.6, col % 100, col).astype(np.int32)
+    key = np.unique(row.astype(np.int64) * m + col)
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    val = rng.random(key.size, dtype=np.float32) + 0.1
+    F = 256
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    bad_inf, bad_nan = 7, 1203
+    B[bad_inf] = np.inf
+    B[bad_nan] = np.nan
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    S = spmm_cpp.StripPlan(blk, 1.0, 256, min_tile_nnz=64)
+    assert S.share > 0.5
+    plan = spmm_cpp.StripHybridPlan(S, spmm_cpp.SegPlan(S.rest, 1))
+    Cg = torch.full((n, F), float('nan'), device=dev)
+    spmm_cpp.spmm_plan(blk, spmm_cpp.pad_rows(torch.from_numpy(B).to(dev)), Cg, 1.0, 0.0, plan)
+    got = Cg.cpu().numpy()
+    touched = np.zeros(n, dtype=bool)
+    touched[row[(col == bad_inf) | (col == bad_nan)]] = True
+    assert touched.any() and not touched.all()
+    assert np.isfinite(got[~touched]).all() and not np.isfinite(got[touched]).all(axis=1).any()
+    # signed zeros: C = -0.0 and a matrix whose products are all -0.0 or absent
+    Bz = np.zeros((m, F), dtype=np.float32)
+    Cz = torch.full((n, F), -0.0, device=dev)
+    neg = _gpu_block(row, col, -np.abs(val), n, m)
+    Sz = spmm_cpp.StripPlan(neg, 1.0, 256, min_tile_nnz=64)
+    spmm_cpp.spmm_plan(neg, spmm_cpp.pad_rows(torch.from_numpy(Bz).to(dev)), Cz, 1.0, 1.0, spmm_cpp.StripHybridPlan(Sz, spmm_cpp.SegPlan(Sz.rest, 1)))
+    assert bool(torch.signbit(Cz).all())                                   # -0.0 + (-a) * (+0.0) = -0.0, pads included
+
+
 def test_dense_entry_point_rejects_bad_arguments():
     import spmm_cpp
     lib = spmm_cpp.lib

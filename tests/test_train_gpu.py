@@ -86,6 +86,11 @@ def test_layer_and_training_curve_on_gpu(env, golden_dir, name):
         assert np.abs(got.detach().cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max(), key   # north_star: 1e-5 relative
     losses = dist_train.train(pg, env, total_epoch=5)
     np.testing.assert_allclose(np.array(losses), w['r0_losses'], rtol=1e-4, atol=1e-4)           # curves overlay
+    # ... and so do the accuracies: the Train / Val / Test lines the reference's train() logged (dist_train.py:48-55)
+    gold_acc = [str(x) for x in w['r0_acc_lines']]
+    with open(env.logger.log_fname) as f:
+        acc = [ln.split('] ', 1)[1].strip() for ln in f if '] Epoch: ' in ln][-len(gold_acc):]
+    assert gold_acc and acc == gold_acc, (acc, gold_acc)
     assert 'spmm' in env.timer.summary() and env.timer.count_dict['spmm'] > 0
     import dist_utils
     import torch.cuda.tunable as tunable
@@ -284,3 +289,24 @@ def test_golden_loss_curve_with_tuned_library_gemms(tmp_path):
         files = glob.glob(os.path.join(str(tmp_path), 'tunableop*.csv'))
         assert any('Gemm' in open(f).read() for f in files) == (mode == '1'), files
     assert set(glob.glob(os.path.join(ROOT, '*.csv'))) == before
+
+
+@pytest.mark.parametrize('n,fin,fout', [(232965, 602, 256), (232965, 256, 41), (70000, 100, 47), (65536 + 3, 128, 64)])
+def test_weight_gradient_product_on_long_blocks(n, fin, fout):
+    """grad_weight = features^T @ ag (gcn.py:50) takes the 4-way split-K form from 65 536 rows up -- every epoch of the
+    headline benchmark does -- : against the fp64 product, within north_star's 1e-5 (relative to the largest entry), at the
+    Reddit layer shapes, with a row count that does not divide by 4, and no worse than the single library call."""
+    from models import gcn
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev)
+    g.manual_seed(n + fin)
+    H = torch.rand(n, fin, device=dev, generator=g)                 # activations after ReLU: non-negative, like the model's
+    ag = torch.randn(n, fout, device=dev, generator=g) * 1e-3
+    want = H.double().t() @ ag.double()
+    scale = want.abs().max().item()
+    got = gcn.grad_weight_product(H, ag)
+    plain = torch.mm(H.t(), ag)
+    err = (got.double() - want).abs().max().item() / scale
+    err_plain = (plain.double() - want).abs().max().item() / scale
+    assert got.shape == (fin, fout) and err <= 1e-5, (err, err_plain)
+    assert err <= 2 * err_plain + 1e-7, (err, err_plain)

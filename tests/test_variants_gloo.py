@@ -281,6 +281,14 @@ def _cpu_gather(src, idx, dst):
     return dst
 
 
+def scenario_adaptive_oracle(env, rank, world, gold_dir):
+    """The host logic of the adaptive policy (decisions, caches, layer stack) against the oracle's restatement, on the CPU
+    (SpMM = the oracle's chain through the test hook); the GPU suite runs the same comparison with the HIP kernels."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_zy_variants_gpu import adaptive_vs_oracle
+    return {(name, L): adaptive_vs_oracle(env, rank, world, gold_dir, name, L, False) for name, L in (('tiny', 2), ('ragged', 3))}
+
+
 def _worker(rank, world, port, scenario, log_dir, q):
     try:
         for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
@@ -349,6 +357,17 @@ def test_adaptive_policy(tmp_path):
         # 4 epochs x (layer1, layer2, 2 backward passes) x 1 remote block; layer1 sent once; layer2 twice when reused
         assert res['never']['transfers'] == 2 * (1 + 4 + 8)
         assert res['always']['transfers'] == 2 * (1 + 2 + 8)
+
+
+def test_adaptive_policy_matches_its_oracle(tmp_path):
+    out = _run(3, 'adaptive_oracle', str(tmp_path))
+    for r, both in out.items():
+        for (name, L), res in both.items():
+            assert res['use2'] == res['want_use2'], (r, name, res)
+            flat = [u for e in res['use2'][1:] for u in e]
+            assert any(flat) and not all(flat)
+            assert res['z1_exact'] and max(res['z_err'].values()) <= 1e-5 and res['loss_err'] <= 1e-5, (r, name, res)
+            assert set(res['z_err']) == {f'layer{i + 1}' for i in range(L)}
 
 
 def test_transform_first_is_the_same_layer(tmp_path):

@@ -21,7 +21,9 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0)
     ap.add_argument('--F', default='602,256')
     ap.add_argument('--max-ratio', default='0.5')
-    ap.add_argument('--piece', default='512')
+    ap.add_argument('--piece', default='256')
+    ap.add_argument('--block', default='26', help='entries a wave should find in one strip (sets the strip width per tile)')
+    ap.add_argument('--variants', default='', help='library debug variants to time the strip kernel with (502: no fills)')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--no-base', action='store_true')
     args = ap.parse_args()
@@ -47,11 +49,11 @@ def main():
             base[F] = med
             print(f'F={F:4d} whole block, {type(pl).__name__:10s}: {med:8.3f} ms (best {best:.3f})', flush=True)
     for mr in [float(x) for x in args.max_ratio.split(',')]:
-        for piece in [int(x) for x in args.piece.split(',')]:
+        for piece, block in [(int(x), float(y)) for x in args.piece.split(',') for y in args.block.split(',')]:
             t0 = time.perf_counter()
-            S = spmm_cpp.StripPlan(A, mr, piece)
+            S = spmm_cpp.StripPlan(A, mr, piece, block_target=block)
             torch.cuda.synchronize()
-            print(f'# strip plan max_ratio={mr} piece={piece}: built in {time.perf_counter()-t0:.2f}s; share {S.share:.3f} of nnz, '
+            print(f'# strip plan max_ratio={mr} piece={piece} block={block}: built in {time.perf_counter()-t0:.2f}s; share {S.share:.3f} of nnz, '
                   f'union/nnz {S.union_ratio:.3f}, {S.tiles} of {S.ntile} tiles, {S.npiece} pieces, {S.ncut} cut rows, '
                   f'{S.npartial} partial rows, entry slots per nonzero {S.padding:.3f}, {S.nbytes/1e9:.2f} GB; rest nnz {S.rest.nnz/1e6:.2f} M', flush=True)
             for F in Fs:
@@ -66,7 +68,7 @@ def main():
                 ok = bool(same[hp.uncut_rows()].all())
                 med, best = time_call(lambda: spmm_cpp.spmm_plan(A, Bp, C, 1.0, 1.0, hp), args.iters, 2)
                 ms, _ = time_call(lambda: spmm_cpp.spmm_strip(S, Bp, C, 1.0), args.iters, 2)
-                for v in (501, 502, 503):
+                for v in [int(x) for x in args.variants.split(',') if x]:
                     spmm_cpp.set_variant(v)
                     mv, _ = time_call(lambda: spmm_cpp.spmm_strip(S, Bp, C, 1.0), args.iters, 2)
                     print(f'    variant {v} (1: no FMAs, 2: no fills): strips {mv:.3f} ms', flush=True)

@@ -18,7 +18,9 @@ all_gather_then_cat, barrier_all): the real one creates log directories inside t
 tree (logger.py:8-9) and calls torch.cuda.synchronize() (timer.py:17-18), which needs a GPU.
 
 The vectors written are data only (inputs + the reference's outputs), stored with numpy
-(no pickle). Usage:  python tests/golden/make_golden.py
+(no pickle). Usage:  python tests/golden/make_golden.py            (everything)
+                     python tests/golden/make_golden.py --worlds 4  (only <name>_P4.npz of tiny and ragged: the 1D
+                     reference at four ranks, what every replica of the 8-rank 1.5D run must reproduce)
 """
 import contextlib
 import importlib.util
@@ -215,6 +217,9 @@ def run_world(tmp_root, name, world, port, epochs=5):
 
 
 def main():
+    only_worlds = None
+    if '--worlds' in sys.argv:
+        only_worlds = tuple(int(x) for x in sys.argv[sys.argv.index('--worlds') + 1].split(','))
     tmp_root = tempfile.mkdtemp(prefix='dgnn_golden_')
     _orig_load = torch.load
     torch.load = lambda p, *a, **k: _orig_load(p, *a, weights_only=False, **k)
@@ -247,11 +252,14 @@ def main():
                     save[f'split_P{P}_dim{dim}_part{j}_idx'] = idx
                     save[f'split_P{P}_dim{dim}_part{j}_val'] = val
                     save[f'split_P{P}_dim{dim}_part{j}_shape'] = np.array(part.shape, dtype=np.int64)
-        np.savez_compressed(os.path.join(OUT, f'{name}_graph.npz'), **save)
-        print('wrote', name, 'graph;', 'nnz', save['adj_val'].size)
+        if only_worlds is None:
+            np.savez_compressed(os.path.join(OUT, f'{name}_graph.npz'), **save)
+            print('wrote', name, 'graph;', 'nnz', save['adj_val'].size)
 
         # COO_Graph(name).partition(P) + Parted_COO_Graph + layers under gloo
-        worlds = (1, 2, 3) if name in ('tiny', 'ragged') else (2,)
+        worlds = (1, 2, 3, 4) if name in ('tiny', 'ragged') else (2,)
+        if only_worlds is not None:
+            worlds = tuple(P for P in only_worlds if name in ('tiny', 'ragged'))
         for P in worlds:
             with contextlib.redirect_stdout(open(os.devnull, 'w')):
                 full = pcg.COO_Graph(name, full_graph_cache_enabled=False)

@@ -342,6 +342,16 @@ def test_15d_matches_1d(tmp_path):
         np.testing.assert_allclose(res['losses'], res['gold_losses'], rtol=2e-4)   # same model as 1D at P = 2
 
 
+def test_15d_schedule_at_8_ranks(tmp_path):
+    """dist_15d.py:68-75 at P = 8, c = 2 (BASELINE config 4): two stages per replica, owners 0, 2 / 5, 7; every replica's z
+    against the reference's 1D run at four ranks (tests/golden/tiny_P4.npz)."""
+    out = _run(8, '15d', str(tmp_path))
+    for r, res in out.items():
+        assert res['stages'] == ([(0, 0), (2, 1)] if r % 2 == 0 else [(5, 2), (7, 3)]), (r, res['stages'])
+        assert res['z'] <= 1e-5, res
+        np.testing.assert_allclose(res['losses'], res['gold_losses'], rtol=2e-4)
+
+
 def test_adaptive_policy(tmp_path):
     out = _run(2, 'adaptive', str(tmp_path))
     for r, res in out.items():

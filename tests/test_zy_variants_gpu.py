@@ -121,19 +121,19 @@ def scenario_transposed(env, rank, world, gold_dir):
     return res
 
 
-def scenario_15d(env, rank, world, gold_dir):
-    """1.5D, c = 2, four ranks: every replica's z equals the reference's 1D z of its row block at P = 2 (tiny_P2), and
-    training follows the 1D golden loss curve (the model is the same function of the graph)."""
+def scenario_15d(env, rank, world, gold_dir, name='tiny'):
+    """1.5D, c = 2: every replica's z equals the reference's 1D z of its row block at P = world / 2 (<name>_P<world/2>),
+    and training follows the 1D golden loss curve (the model is the same function of the graph)."""
     import coo_graph
     import dist_train
     from models import gcn_15d, GCN15D
     dev, rep = env.device, 2
-    gold = np.load(os.path.join(gold_dir, 'tiny_graph.npz'))
+    gold = np.load(os.path.join(gold_dir, f'{name}_graph.npz'))
     nb = world // rep
-    w = np.load(os.path.join(gold_dir, f'tiny_P{nb}.npz'))
-    full = coo_graph.COO_Graph('tiny', attr_dict=_raw(gold, 'cpu'))
+    w = np.load(os.path.join(gold_dir, f'{name}_P{nb}.npz'))
+    full = coo_graph.COO_Graph(name, attr_dict=_raw(gold, 'cpu'))
     blk = rank // rep
-    g = coo_graph.Parted_COO_Graph('tiny', blk, nb, device=dev, attr_dict=full.partition(nb, save=False)[blk])
+    g = coo_graph.Parted_COO_Graph(name, blk, nb, device=dev, attr_dict=full.partition(nb, save=False)[blk])
     g.features = torch.from_numpy(w[f'r{blk}_features']).to(dev)
     r = gcn_15d.init_rep(rep)
     z = gcn_15d.broadcast_15d(g.adj_parts, g.features, 'ForwardL1')
@@ -312,6 +312,22 @@ def test_15d_replication_matches_the_1d_reference(tmp_path):
     assert out[2]['stages'] == [(0, 0)] and out[3]['stages'] == [(3, 1)]
     for r, res in out.items():
         assert res['z'] <= 1e-5, res
+        np.testing.assert_allclose(res['losses'], res['gold_losses'], rtol=2e-4)
+
+
+@pytest.mark.parametrize('world,name', [(8, 'tiny'), (8, 'ragged'), (6, 'tiny')])
+def test_15d_replication_at_8_and_6_ranks(world, name, tmp_path):
+    """BASELINE config 4 is stated at 8 GPUs: the 8-rank schedule (1D_CAGNET/dist_15d.py:68-75: stages = P / c^2 = 2 per
+    replica, owner q = am_partid * c + rank_col) against the reference's 1D run at four ranks (tests/golden/*_P4.npz, made
+    by make_golden.py --worlds 4), and 6 ranks for the remainder rule (:70-71: the last replica takes 3 - 1 = 2 stages)."""
+    out = _run(world, '15d', str(tmp_path), name)
+    if world == 8:
+        want = {0: [(0, 0), (2, 1)], 1: [(5, 2), (7, 3)]}
+    else:
+        want = {0: [(0, 0)], 1: [(3, 1), (5, 2)]}
+    for r, res in out.items():
+        assert res['stages'] == want[r % 2], (r, res['stages'])
+        assert res['z'] <= 1e-5, (r, res)
         np.testing.assert_allclose(res['losses'], res['gold_losses'], rtol=2e-4)
 
 

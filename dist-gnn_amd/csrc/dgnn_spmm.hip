@@ -41,6 +41,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "dgnn_spmm.h"
@@ -48,7 +50,14 @@
 namespace {
 
 thread_local char g_err[512] = "";
+// A/B knobs of tools/*_bench.py (lane-group widths, gathers in flight, parts of a kernel switched off for timing): they
+// exist only in a library built with -DDGNN_EXPERIMENTS (lib/libdgnn_spmm_exp.so, declared in
+// include/dgnn_spmm_experiments.h). In the product build the knob is a constant 0 and every branch on it folds away.
+#ifdef DGNN_EXPERIMENTS
 int g_variant = 0;
+#else
+constexpr int g_variant = 0;
+#endif
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
   snprintf(g_err, sizeof(g_err), fmt, a, b);
@@ -64,18 +73,21 @@ int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
 
 // Optional in-library timing of the SpMM kernels with HIP events on the launch stream
 // (dgnn_prof_begin / dgnn_prof_end): bench.py uses it for the live roofline figure.
+// kinds: the SpMM kernels one by one, then the helpers (DGNN_PROF_* in the header)
+enum { K_STAGE = 0, K_BUNDLE = 1, K_DENSE = 2, K_STRIP = 3, K_HOT = 4, K_ROWS = 5, K_MERGE = 6, K_HELPER = 7, K_COUNT = 8 };
 struct ProfRec { hipEvent_t a, b; int kind; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;                         // launches may come from several host threads (forward / autograd engine)
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
   hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(hipStream_t s_, int kind_) : s(s_), kind(kind_) {
-    if (g_prof_on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+    if (g_prof_on.load(std::memory_order_relaxed) && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
     else a = nullptr;
   }
   ~ProfScope() {
-    if (a) { (void)hipEventRecord(b, s); g_prof.push_back({a, b, kind}); }
+    if (a) { (void)hipEventRecord(b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back({a, b, kind}); }
   }
 };
 
@@ -1063,7 +1075,7 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
   while (s < nsp) {
     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");            // all but the youngest line request have landed
     if (first) {
-      __builtin_amdgcn_s_barrier();                             // everybody's slices of s are in; everybody is done with s - 1
+      if (!(dbg & 4)) __builtin_amdgcn_s_barrier();             // everybody's slices of s are in; everybody is done with s - 1
       if (s + 1 < nsp) STRIP_FILL(s + 1, c0, c1, c2, c3)
     }
     asm volatile("" ::: "memory");
@@ -1397,6 +1409,7 @@ int launch_rows(const Args& a) {
   const int W = a.F / VW;
   const int gy = (W + L * NPASS - 1) / (L * NPASS);
   if (gx <= 0 || gx > 0x7fffffffLL || gy > 65535) return fail(DGNN_E_BADARG, "grid out of range%s (%lld)", "", gx);
+  ProfScope prof(a.s, K_ROWS);
   hipLaunchKernelGGL((spmm_rows_kernel<VW, L, NPASS>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, a.s,
                      a.rowptr, a.col, a.val, a.n, a.B, a.ldb, a.C, a.ldc, a.F, a.alpha, a.beta);
   DGNN_HIP(hipGetLastError());
@@ -1451,7 +1464,7 @@ int launch_stage(int vwc, bool wide, const int4* seg, int32_t nseg, const int32_
   if (g_variant >= 404 && g_variant < 408) k = 0;
   const int64_t nb = nsegblocks * nchunks;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "stage grid out of range%s (%lld)", "", nb);
-  ProfScope prof(s, 0);
+  ProfScope prof(s, K_STAGE);
 #define DGNN_STAGE(VWC, WIDE)                                                                             \
   hipLaunchKernelGGL((spmm_stage_kernel<L, U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, seg, nseg, \
                      (uint32_t)nsegblocks, col, val, B, ldb, C, ldc, P, ldp, F, alpha, k, fresh ? 1 : 0)
@@ -1485,7 +1498,7 @@ int launch_hot(int vwc, bool wide, const int4* seg, const int32_t* seg_hot, int3
     if (cus < 8) cus = 8;
   }
   const unsigned grid = (unsigned)(nbv < cus ? nbv : cus);
-  ProfScope prof(s, 0);
+  ProfScope prof(s, K_HOT);
 #define DGNN_HOT(VWC, WIDE)                                                                                     \
   hipLaunchKernelGGL((spmm_hot_kernel<L, U, VWC, WIDE>), dim3(grid), dim3(HOT_WAVES * 64), 0, s, seg, seg_hot, nseg, \
                      (uint32_t)nsegblocks, (uint32_t)nbv, col, val, hot_cols, B, ldb, C, ldc, P, ldp, F, alpha, k, fresh ? 1 : 0, \
@@ -1511,7 +1524,7 @@ int launch_bundle(int vwc, bool wide, const int32_t* desc, int32_t ndesc, const 
   nsegblocks = (nsegblocks + k - 1) / k * k;
   const int64_t nb = nsegblocks * nchunks;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(DGNN_E_BADARG, "bundle grid out of range%s (%lld)", "", nb);
-  ProfScope prof(s, 0);
+  ProfScope prof(s, K_BUNDLE);
 #define DGNN_BUNDLE(VWC, WIDE)                                                                                 \
   hipLaunchKernelGGL((spmm_bundle_kernel<R, L, U, VWC, WIDE>), dim3((unsigned)nb), dim3(256), 0, s, desc, ndesc, \
                      (uint32_t)nsegblocks, ucol, uval, B, ldb, C, ldc, P, ldp, F, alpha, k, fresh ? 1 : 0)
@@ -1558,37 +1571,50 @@ size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" {
 
-int dgnn_version(void) { return 260; }   // 260: dgnn_strip_plan, dgnn_spmm_strip_f32; 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
+int dgnn_version(void) { return 260; }   // 260: dgnn_strip_plan, dgnn_spmm_strip_f32, dgnn_prof_end_by_kernel, dgnn_set_variant only in -DDGNN_EXPERIMENTS builds; 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 
 int dgnn_prof_begin(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();
-  g_prof_on = true;
+  g_prof_on.store(true);
   return DGNN_OK;
+}
+
+int dgnn_prof_end_by_kernel(double* ms, int64_t* launches, int32_t count) {
+  g_prof_on.store(false);
+  if (count < 0 || (count > 0 && (!ms || !launches))) return fail(DGNN_E_BADARG, "prof_end_by_kernel: bad argument%s", "");
+  std::vector<ProfRec> recs;
+  { std::lock_guard<std::mutex> lk(g_prof_mu); recs.swap(g_prof); }
+  for (int k = 0; k < count; ++k) { ms[k] = 0; launches[k] = 0; }
+  int rc = DGNN_OK;
+  for (auto& r : recs) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = fail(DGNN_E_HIP, "prof_end: event query failed%s", "");
+    else if (r.kind < count) { ms[r.kind] += t; launches[r.kind] += 1; }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  return rc;
 }
 
 int dgnn_prof_end(double* stage_ms, int64_t* stage_launches, double* other_ms, int64_t* other_launches) {
-  g_prof_on = false;
-  double ms[2] = {0, 0}; int64_t cnt[2] = {0, 0};
-  for (auto& r : g_prof) {
-    float t = 0.f;
-    DGNN_HIP(hipEventSynchronize(r.b));
-    DGNN_HIP(hipEventElapsedTime(&t, r.a, r.b));
-    ms[r.kind] += t; cnt[r.kind] += 1;
-    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
-  }
-  g_prof.clear();
-  if (stage_ms) *stage_ms = ms[0];
-  if (stage_launches) *stage_launches = cnt[0];
-  if (other_ms) *other_ms = ms[1];
-  if (other_launches) *other_launches = cnt[1];
-  return DGNN_OK;
+  double ms[K_COUNT]; int64_t cnt[K_COUNT];
+  const int rc = dgnn_prof_end_by_kernel(ms, cnt, K_COUNT);
+  double a = 0, o = 0; int64_t na = 0, no = 0;
+  for (int k = 0; k < K_COUNT; ++k) { if (k < K_MERGE) { a += ms[k]; na += cnt[k]; } else { o += ms[k]; no += cnt[k]; } }
+  if (stage_ms) *stage_ms = a;
+  if (stage_launches) *stage_launches = na;
+  if (other_ms) *other_ms = o;
+  if (other_launches) *other_launches = no;
+  return rc;
 }
 
+#ifdef DGNN_EXPERIMENTS
 int dgnn_set_variant(int variant) { g_variant = variant; return DGNN_OK; }
 int dgnn_get_variant(void) { return g_variant; }
+#endif
 
 int dgnn_coo2csr_i32(const int32_t* row, int64_t nnz, int32_t n, int32_t* rowptr, void* stream) {
   if (n < 0 || nnz < 0 || nnz > 0x7fffffffLL) return fail(DGNN_E_BADARG, "coo2csr: bad sizes%s (nnz=%lld)", "", nnz);
@@ -1616,7 +1642,7 @@ int dgnn_pad_rows_f32(const float* src, int64_t lds, float* dst, int64_t ldd, in
   if (lds < F || ldd < F || ldd % 4 != 0 || !aligned(dst, 16))
     return fail(DGNN_E_BADARG, "pad_rows: need lds >= F, ldd >= F, ldd %% 4 == 0, dst 16-byte aligned%s", "");
   if (overlap(src, n, lds, dst, n, ldd, F)) return fail(DGNN_E_BADARG, "pad_rows: src and dst overlap%s", "");
-  ProfScope prof((hipStream_t)stream, 1);
+  ProfScope prof((hipStream_t)stream, K_HELPER);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(capped_blocks((int64_t)n * (ldd / 4), 16384)), dim3(256), 0,
                      (hipStream_t)stream, src, lds, dst, ldd, n, F);
   DGNN_HIP(hipGetLastError());
@@ -1633,7 +1659,7 @@ int dgnn_gather_rows_f32(const float* src, int64_t lds, int32_t nsrc, const int3
     return fail(DGNN_E_BADARG, "gather_rows: need lds >= F, ldd >= F, ldd %% 4 == 0, dst 16-byte aligned%s", "");
   if (overlap(src, nsrc, lds, dst, k, ldd, F)) return fail(DGNN_E_BADARG, "gather_rows: src and dst overlap%s", "");
   const bool src_vec4 = (lds % 4 == 0) && aligned(src, 16);
-  ProfScope prof((hipStream_t)stream, 1);
+  ProfScope prof((hipStream_t)stream, K_HELPER);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(capped_blocks((int64_t)k * (ldd / 4), 16384)), dim3(256), 0,
                      (hipStream_t)stream, src, lds, idx, dst, ldd, k, F, src_vec4);
   DGNN_HIP(hipGetLastError());
@@ -1798,7 +1824,7 @@ int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
   // product with beta == 0 overwrites C without a zero fill and without reading it
   const bool overwrite = beta == 0.f && !empty && plan->stage_desc_off[1] > plan->stage_desc_off[0];
   if (beta != 1.f && !overwrite) {
-    ProfScope prof(s, 1);
+    ProfScope prof(s, K_HELPER);
     hipLaunchKernelGGL(scale_rows_kernel, dim3(capped_blocks((int64_t)n * F, 8192)), dim3(256), 0, s, C, ldc, n, F, beta);
     DGNN_HIP(hipGetLastError());
   }
@@ -1833,7 +1859,7 @@ int dgnn_spmm_bundle_f32(const dgnn_bundle_plan* plan, int32_t n, int32_t m,
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
     if (p1 > p0) {
-      ProfScope prof(s, 1);
+      ProfScope prof(s, K_HELPER);
       const int32_t nc = (int32_t)(p1 - p0);
       const int4* cutp = reinterpret_cast<const int4*>(plan->cut) + p0;
       launch_merge(vwc, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0, s);
@@ -1868,7 +1894,7 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
   const int vw2 = (ldc % 2 == 0 && aligned(C, 8)) ? 1 : 0;
   const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : (vw2 ? 2 : 1);
   {
-    ProfScope prof(s, 0);
+    ProfScope prof(s, K_DENSE);
     const dim3 grid((unsigned)((nitems + 3) / 4));
     const int4* desc = reinterpret_cast<const int4*>(plan->desc);
 #define DGNN_DENSE(A1, D, WW)                                                                                          \
@@ -1876,18 +1902,20 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
                        plan->kcol, plan->kval, B, ldb, C, ldc, partial, ldp, F, alpha, vw2)
     if (w == 1) { if (alpha != 1.f) DGNN_DENSE(false, 0, 1); else DGNN_DENSE(true, 0, 1); }
     else if (alpha != 1.f) DGNN_DENSE(false, 0, 2);
+#ifdef DGNN_EXPERIMENTS                          // parts of the kernel switched off, for timing (results are wrong)
     else if (g_variant == 301) DGNN_DENSE(true, 1, 2);
     else if (g_variant == 302) DGNN_DENSE(true, 2, 2);
     else if (g_variant == 303) DGNN_DENSE(true, 3, 2);
     else if (g_variant == 307) DGNN_DENSE(true, 7, 2);
     else if (g_variant == 311) DGNN_DENSE(true, 11, 2);
     else if (g_variant == 315) DGNN_DENSE(true, 15, 2);
+#endif
     else DGNN_DENSE(true, 0, 2);
 #undef DGNN_DENSE
     DGNN_HIP(hipGetLastError());
   }
   if (plan->ncut > 0) {
-    ProfScope prof(s, 1);
+    ProfScope prof(s, K_MERGE);
     const int4* cutp = reinterpret_cast<const int4*>(plan->cut);
     launch_merge(vwc, cutp, plan->ncut, partial, ldp, C, ldc, F, 0, s);
     DGNN_HIP(hipGetLastError());
@@ -1921,14 +1949,14 @@ int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
   const int vw2 = (ldc % 2 == 0 && aligned(C, 8)) ? 1 : 0;
   const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : (vw2 ? 2 : 1);
   {
-    ProfScope prof(s, 0);
+    ProfScope prof(s, K_STRIP);
     hipLaunchKernelGGL(spmm_strip_kernel, dim3((unsigned)nitems), dim3(STRIP_NW * 64), 0, s, plan->desc, plan->npiece, plan->rows,
                        plan->ucol, plan->ent, plan->ebase, B, ldb, C, ldc, partial, ldp, F, vw2,
-                       g_variant == 502 ? 2 : 0);
+                       g_variant == 502 ? 2 : (g_variant == 504 ? 4 : (g_variant == 506 ? 6 : 0)));   // timing experiments: 2 no fills, 4 no barrier (wrong sums, in-bounds)
     DGNN_HIP(hipGetLastError());
   }
   if (plan->ncut > 0) {
-    ProfScope prof(s, 1);
+    ProfScope prof(s, K_MERGE);
     launch_merge(vwc, reinterpret_cast<const int4*>(plan->cut), plan->ncut, partial, ldp, C, ldc, F, 0, s);
     DGNN_HIP(hipGetLastError());
   }
@@ -1950,7 +1978,7 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
   // beta == 0 with a plan whose first stage lists every row: nothing to prepare, C is overwritten
   const bool overwrite = beta == 0.f && !empty && plan->covers_rows != 0 && plan->stage_seg_off[1] > plan->stage_seg_off[0];
   if (beta != 1.f && !overwrite) {
-    ProfScope prof(s, 1);
+    ProfScope prof(s, K_HELPER);
     hipLaunchKernelGGL(scale_rows_kernel, dim3(capped_blocks((int64_t)n * F, 8192)), dim3(256), 0, s, C, ldc, n, F, beta);
     DGNN_HIP(hipGetLastError());
   }
@@ -2017,7 +2045,7 @@ static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float
     }
     const int64_t p0 = plan->stage_cut_off[st], p1 = plan->stage_cut_off[st + 1];
     if (p1 > p0) {
-      ProfScope prof(s, 1);
+      ProfScope prof(s, K_HELPER);
       const int32_t nc = (int32_t)(p1 - p0);
       const int4* cutp = reinterpret_cast<const int4*>(plan->cut) + p0;
       launch_merge(vwc, cutp, nc, partial, ldp, C, ldc, F, fresh ? 1 : 0, s);

@@ -66,10 +66,9 @@ class _CLayout(ctypes.Structure):        # struct dgnn_plan_layout (include/dgnn
 _pi64 = ctypes.POINTER(ctypes.c_int64)
 _SIGNATURES = {                          # argument types, in the order of include/dgnn_spmm.h; all return int
     'dgnn_version': [],
-    'dgnn_set_variant': [ctypes.c_int],
-    'dgnn_get_variant': [],
     'dgnn_prof_begin': [],
     'dgnn_prof_end': [ctypes.POINTER(ctypes.c_double), _pi64, ctypes.POINTER(ctypes.c_double), _pi64],
+    'dgnn_prof_end_by_kernel': [ctypes.POINTER(ctypes.c_double), _pi64, _i32],
     'dgnn_coo2csr_i32': [_p, _i64, _i32, _p, _p],
     'dgnn_idx_i64_to_i32': [_p, _i64, _p, _p],
     'dgnn_pad_rows_f32': [_p, _i64, _p, _i64, _i32, _i32, _p],
@@ -264,7 +263,26 @@ def prof_end():
     return dict(stage_ms=a.value, stage_launches=na.value, other_ms=b.value, other_launches=nb.value)
 
 
+PROF_KERNELS = ('stage', 'bundle', 'dense', 'strip', 'hot', 'rows', 'merge', 'helper')     # DGNN_PROF_* of the header
+
+
+def prof_end_by_kernel():
+    """-> {kernel: (ms, launches)} since prof_begin(), kernels as in PROF_KERNELS."""
+    n = len(PROF_KERNELS)
+    ms, cnt = (ctypes.c_double * n)(), (ctypes.c_int64 * n)()
+    _check(_lib.dgnn_prof_end_by_kernel(ms, cnt, n), 'prof_end_by_kernel')
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KERNELS)}
+
+
 def set_variant(v):
+    """A/B knob of the benchmark tools: only in a library built with -DDGNN_EXPERIMENTS (include/dgnn_spmm_experiments.h;
+    DGNN_LIB=.../lib/libdgnn_spmm_exp.so). The product library has no such switch."""
+    if not hasattr(_lib, 'dgnn_set_variant'):
+        if int(v) == 0:
+            return
+        raise RuntimeError('spmm_cpp.set_variant: this is the product library; load the experiments build '
+                           '(DGNN_LIB=<repo>/dist-gnn_amd/lib/libdgnn_spmm_exp.so) for the A/B knobs')
+    _lib.dgnn_set_variant.argtypes = [ctypes.c_int]
     _check(_lib.dgnn_set_variant(int(v)), 'set_variant')
 
 
@@ -1072,13 +1090,13 @@ class StripPlan:
         dev = A.device
         n, m, nnz = A.n, A.m, A.nnz
         if max_ratio is None:
-            max_ratio = float(os.environ.get('DGNN_STRIP_MAX_RATIO', 0.5))
+            max_ratio = float(os.environ.get('DGNN_STRIP_MAX_RATIO', 0.8))
         if piece_strips is None:
-            piece_strips = int(os.environ.get('DGNN_STRIP_PIECE', 256))
+            piece_strips = int(os.environ.get('DGNN_STRIP_PIECE', 512))
         if min_tile_nnz is None:
             min_tile_nnz = int(os.environ.get('DGNN_STRIP_MIN_TILE_NNZ', 1024))
         if block_target is None:
-            block_target = float(os.environ.get('DGNN_STRIP_BLOCK', 26))
+            block_target = float(os.environ.get('DGNN_STRIP_BLOCK', 52))
         if piece_strips < 1:
             raise ValueError('piece_strips must be positive')
         self.max_ratio, self.piece_strips = float(max_ratio), int(piece_strips)

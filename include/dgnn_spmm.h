@@ -369,20 +369,24 @@ int dgnn_spmm_coo_noalloc_f32(const int32_t* row, const int32_t* col, const floa
                               float alpha, float beta, void* stream);
 
 /*
- * Measurement hooks (no counterpart in the reference). Between dgnn_prof_begin() and
- * dgnn_prof_end() every kernel launch of dgnn_spmm_plan_f32 / dgnn_pad_rows_f32 is bracketed by
- * HIP events on its own stream. dgnn_prof_end() waits for them and returns the summed
- * durations: the stage SpMM kernels (stage_*) and the helper kernels -- pad, beta scale,
- * merge -- (other_*). Not thread-safe; adds two event records per launch while enabled.
+ * Measurement hooks (no counterpart in the reference). Between dgnn_prof_begin() and dgnn_prof_end...() every kernel
+ * launch of the library is bracketed by HIP events on its own stream. dgnn_prof_end() waits for them and returns the
+ * summed durations of the SpMM kernels (stage_*) and of the helper kernels -- pad, gather, beta scale, merge --
+ * (other_*); dgnn_prof_end_by_kernel() returns them per kernel: ms[k], launches[k] for k < count, k one of DGNN_PROF_*.
+ * Thread-safe (the record list is mutex-guarded); adds two event records per launch while enabled.
  */
+#define DGNN_PROF_STAGE 0   /* spmm_stage_kernel */
+#define DGNN_PROF_BUNDLE 1  /* spmm_bundle_kernel */
+#define DGNN_PROF_DENSE 2   /* spmm_dense_kernel */
+#define DGNN_PROF_STRIP 3   /* spmm_strip_kernel */
+#define DGNN_PROF_HOT 4     /* spmm_hot_kernel */
+#define DGNN_PROF_ROWS 5    /* spmm_rows_kernel */
+#define DGNN_PROF_MERGE 6   /* merge_kernel (partial rows of cut runs / bundles / tiles) */
+#define DGNN_PROF_HELPER 7  /* pad, gather, scale */
+#define DGNN_PROF_COUNT 8
 int dgnn_prof_begin(void);
 int dgnn_prof_end(double* stage_ms, int64_t* stage_launches, double* other_ms, int64_t* other_launches);
-
-/*
- * Debug/benchmark knob (0 = default). Not part of the reference interface.
- */
-int dgnn_set_variant(int variant);
-int dgnn_get_variant(void);
+int dgnn_prof_end_by_kernel(double* ms, int64_t* launches, int32_t count);
 
 #ifdef __cplusplus
 }

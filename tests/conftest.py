@@ -24,5 +24,6 @@ os.environ.setdefault('DGNN_POISON', '1')
 
 # dist_train.train() picks the library of every X W shape by timing (dist_utils/gemm.py): which one wins a tiny shape
 # varies from run to run, and tests that compare two runs bit for bit need the same kernels in both. The suite runs on
-# PyTorch's default library; test_train_gpu.py turns the choice on in child processes for the golden loss curve.
+# PyTorch's default library (since round 3 that is also train()'s own default: the choice is opt-in); test_train_gpu.py
+# turns it on in child processes for the golden loss curve.
 os.environ.setdefault('DGNN_TUNE_GEMM', '0')

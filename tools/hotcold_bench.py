@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'dist-gnn_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
+os.environ.setdefault('DGNN_LIB', os.path.join(ROOT, 'dist-gnn_amd', 'lib', 'libdgnn_spmm_exp.so'))   # the build with the A/B knobs
 import spmm_cpp  # noqa: E402
 from kernel_bench import build_graph, time_call  # noqa: E402
 

@@ -12,6 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'dist-gnn_amd'))
+os.environ.setdefault('DGNN_LIB', os.path.join(ROOT, 'dist-gnn_amd', 'lib', 'libdgnn_spmm_exp.so'))   # the build with the A/B knobs
 import spmm_cpp  # noqa: E402
 from coo_graph import synthetic, graph_utils  # noqa: E402
 

@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'dist-gnn_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
+os.environ.setdefault('DGNN_LIB', os.path.join(ROOT, 'dist-gnn_amd', 'lib', 'libdgnn_spmm_exp.so'))   # the build with the A/B knobs
 import spmm_cpp  # noqa: E402
 from kernel_bench import build_graph, time_call  # noqa: E402
 
@@ -26,6 +27,7 @@ def main():
     ap.add_argument('--variants', default='', help='library debug variants to time the strip kernel with (502: no fills)')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--no-base', action='store_true')
+    ap.add_argument('--dense', default='', help='min_count values: dense tiles first (DensePlan), strips on their remainder')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     A, adj = build_graph(args.shape, args.scale, 0, dev)
@@ -48,6 +50,26 @@ def main():
             med, best = time_call(lambda: spmm_cpp.spmm_plan(A, Bp, C, 1.0, 1.0, pl), args.iters, 2)
             base[F] = med
             print(f'F={F:4d} whole block, {type(pl).__name__:10s}: {med:8.3f} ms (best {best:.3f})', flush=True)
+    for mc in [int(x) for x in args.dense.split(',') if x]:
+        D = spmm_cpp.DensePlan(A, min_count=mc)
+        S = spmm_cpp.StripPlan(D.rest, float(args.max_ratio.split(',')[0]), int(args.piece.split(',')[0]), block_target=float(args.block.split(',')[0]))
+        print(f'# dense tiles min_count={mc}: share {D.share:.3f} at density {D.density:.3f}; strips on the remainder: share {S.share:.3f} of its {D.rest.nnz/1e6:.1f} M, '
+              f'union/nnz {S.union_ratio:.3f}, {S.npiece} pieces, slots per nonzero {S.padding:.3f}; rest nnz {S.rest.nnz/1e6:.2f} M', flush=True)
+        for F in Fs:
+            Bp, C0 = ref[F]
+            rp = spmm_cpp._plan_for_sparse(S.rest, F)
+            C = torch.zeros(A.n, F, device=dev)
+            def run():
+                spmm_cpp.spmm_plan(S.rest, Bp, C, 1.0, 0.0, rp)
+                spmm_cpp.spmm_strip(S, Bp, C, 1.0)
+                spmm_cpp.spmm_dense(D, Bp, C, 1.0)
+            run()
+            err = ((C - C0).abs().max() / C0.abs().max()).item()
+            med, best = time_call(run, args.iters, 2)
+            md, _ = time_call(lambda: spmm_cpp.spmm_dense(D, Bp, C, 1.0), args.iters, 2)
+            ms, _ = time_call(lambda: spmm_cpp.spmm_strip(S, Bp, C, 1.0), args.iters, 2)
+            print(f'F={F:4d} tiles + strips + rest: {med:8.3f} ms (best {best:.3f}) = tiles {md:.3f} + strips {ms:.3f} + rest; relerr {err:.1e}', flush=True)
+        del D, S
     for mr in [float(x) for x in args.max_ratio.split(',')]:
         for piece, block in [(int(x), float(y)) for x in args.piece.split(',') for y in args.block.split(',')]:
             t0 = time.perf_counter()

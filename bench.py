@@ -13,9 +13,10 @@ to CSR + work plans BEFORE the timed region; inputs are resident in HBM when tim
 
 Prints ONE JSON line on rank 0. `value` = edges aggregated per second by the whole job: every epoch
 runs 2*L SpMM passes over all nnz(A_hat) entries (L forward + L backward aggregations), so
-value = 2*L*nnz*K / t / 1e9. `roofline` is for the dominant kernel (spmm_stage_kernel), timed
-with HIP events on its launch stream inside the library (dgnn_prof_begin/end) during the timed
-steps. `cpu_baseline` (N = 1 only) is the CPU oracle (the reference's CPU fallback arithmetic restated in C,
+value = 2*L*nnz*K / t / 1e9. `roofline` covers every SpMM kernel launch of the epoch (`roofline.per_kernel`
+splits the time kernel by kernel; `dominant_kernel` names the largest: spmm_strip_kernel on the Reddit shape),
+timed with HIP events on the launch stream inside the library (dgnn_prof_begin / dgnn_prof_end_by_kernel) during
+the timed steps. `cpu_baseline` (N = 1 only) is the CPU oracle (the reference's CPU fallback arithmetic restated in C,
 oracle/spmm_ref.c) over the same SpMMs on the box's host threads, with the reference's fallback itself
 (torch `C.addmm_(A, B)`) timed beside it on a row prefix. Extras on the line: `gpu_ms_per_step` (GPU time under
 the reference's timer keys), `comm` (N > 1), `alt` (N = 1: the opt-in transform-first epoch time, never the
@@ -294,7 +295,10 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = spmm_cpp.prof_end()
+    by_kernel = spmm_cpp.prof_end_by_kernel()
+    spmm_kinds = ('stage', 'bundle', 'dense', 'strip', 'hot', 'rows')
+    prof = dict(stage_ms=sum(by_kernel[k][0] for k in spmm_kinds), stage_launches=sum(by_kernel[k][1] for k in spmm_kinds),
+                other_ms=by_kernel['merge'][0] + by_kernel['helper'][0], other_launches=by_kernel['merge'][1] + by_kernel['helper'][1])
     say(f'{args.steps} timed epochs done')
     env.timer.resolve()
     # GPU time per step under the reference's timer keys (HIP events on the compute stream; 'broadcast' is
@@ -342,7 +346,17 @@ def main():
         traffic = tj.get('hbm_bytes_per_launch')
         traffic_source = ('stored: profiles/traffic.json, rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) '
                           f"of `{tj.get('command', 'python bench.py')}` at {tj.get('commit', 'an earlier commit')}; not measured in this run")
-    roofline = dict(bound='hbm', kernel='spmm_dense_kernel + spmm_bundle_kernel + spmm_stage_kernel (every SpMM launch of the epoch)', achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+    # the same figure kernel by kernel: each kernel's share of the algorithmic bytes = its share of the SpMM calls it serves
+    # is not separable (a call = strips + rest, or tiles + bundles), so the split reports time, launches and the rate the
+    # kernel would need alone: algorithmic bytes of the epoch x (its time share) / its time = the blended rate; what differs
+    # per kernel is ms -- the dominant kernel is the one with the largest `ms_per_step`
+    per_kernel = {k: dict(ms_per_step=round(by_kernel[k][0] / args.steps, 4), launches_per_step=round(by_kernel[k][1] / args.steps, 2),
+                          avg_launch_ms=round(by_kernel[k][0] / by_kernel[k][1], 4))
+                  for k in spmm_cpp.PROF_KERNELS if by_kernel[k][1]}
+    dominant = max((k for k in spmm_kinds if by_kernel[k][1]), key=lambda k: by_kernel[k][0], default=None)
+    roofline = dict(bound='hbm', kernel='every SpMM launch of the epoch: ' + ' + '.join(f'spmm_{k}_kernel' for k in spmm_kinds if by_kernel[k][1]),
+                    dominant_kernel=(f'spmm_{dominant}_kernel' if dominant else None), per_kernel=per_kernel,
+                    achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(alg / launches),
                     avg_launch_ms=round(prof['stage_ms'] / launches, 4), launches=int(launches),

@@ -23,7 +23,7 @@ import tempfile
 
 import torch
 
-_state = {'mode': None, 'picks': {}, 'lib': None, 'tuning': None, 'saved': None}
+_state = {'mode': None, 'picks': {}, 'lib': None, 'tuning': None, 'saved': None, 'last_picks': {}}
 
 
 def _cache_dir():
@@ -80,13 +80,18 @@ def restore():
         tunable.tuning_enable(saved['tuning'])
         tunable.enable(saved['enabled'])
     torch.backends.cuda.preferred_blas_library(saved['lib'])
-    _state.update(mode=None, lib=None, picks={}, tuning=None, saved=None)
+    _state.update(mode=None, lib=None, last_picks=dict(_state['picks']), picks={}, tuning=None, saved=None)
 
 
 def picks():
     """{(op, shapes, strides, ...): 'tunableop' | 'cublas' | 'cublaslt'} decided so far (logs, tests); PyTorch's names:
     cublas = rocBLAS, cublaslt = hipBLASLt."""
     return dict(_state['picks'])
+
+
+def last_picks():
+    """The picks of the run that restore() ended (logs, tests)."""
+    return dict(_state['last_picks'])
 
 
 def _set(lib, tuning):

@@ -559,6 +559,15 @@ class DevicePlan:
     partial = SegPlan.partial
 
 
+def strict():
+    """DGNN_STRICT=1: parity / debugging runs. Row strips, dense tiles and row bundles are off and no run is cut into
+    pieces, so EVERY row is one chain of fused multiply-adds in ascending column order -- the bits of the CPU oracle and
+    of dgnn_spmm_csr_f32 on every row, and a non-finite feature reaches exactly the rows that reference it (dense tiles
+    and bundles give absent entries a zero weight, which turns an Inf or NaN of a neighbour's neighbour into NaN;
+    INTEGRATION.md section 4). Costs about 2x on the Reddit shape."""
+    return os.environ.get('DGNN_STRICT', '0') == '1'
+
+
 def _plan_for(A, F):
     """The resident plan of a block for feature width F, built once. Default: the host-side SegPlan, whose
     lists are exactly longest-first (1.7 % faster per epoch than the 12.5 %-wide length classes of a
@@ -570,6 +579,12 @@ def _plan_for(A, F):
     # sparse remainder. Feature blocks of at least 128 floats only: the tile kernel has a 64-float form too, but its cost
     # is dominated by the value stream, which does not shrink with the width (Reddit shape, F = 41: tiles 0.63 + remainder
     # 1.16 ms against 1.49 ms for the whole block on the stage kernel).
+    if strict():
+        plans = A.__dict__.setdefault('_plans', {})
+        key = ('strict', default_stage_count(A.n, A.m, A.nnz, F))
+        if key not in plans:
+            plans[key] = SegPlan(A, key[1], piece_len=2 ** 31 - 1)
+        return plans[key]
     if padded_width(F) >= 128 and not int(os.environ.get('DGNN_HOT_ROWS', 0) or 0) \
             and os.environ.get('DGNN_PLAN_BUILDER', 'torch') != 'device':
         # Row strips (StripPlan): tiles of 256 rows whose union column list is streamed once through LDS -- one B slice

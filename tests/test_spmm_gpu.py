@@ -634,11 +634,10 @@ def test_full_size_configs_at_their_own_widths(shape, F):
     # row belongs to is cut): there the result is the strict chain
     uncut = plan.uncut_rows()
     if shape == 'reddit' and F >= 128:
-        # hub rows x hub columns run as dense tiles (half of the nonzeros), the remainder through the sparse plan; rows
-        # that belong to no tile (the lighter three quarters) keep the strict chain over ascending columns
-        assert isinstance(plan, spmm_cpp.HybridPlan) and plan.dense.share > 0.4 and plan.dense.density > 0.25
-        uncut = plan.strict_rows()
-        assert int(uncut.sum()) > 0.7 * n
+        # row strips take nearly the whole block (tiles of 256 rows share their columns: one B slice per 6-7 nonzeros);
+        # every row keeps the strict chain over ascending columns except those of the hub tiles whose union list is cut
+        assert isinstance(plan, spmm_cpp.StripHybridPlan) and plan.strip.share > 0.9 and plan.strip.union_ratio < 0.2
+        assert int(uncut.sum()) > 0.8 * n
     else:
         assert int(uncut.sum()) > 0.9 * n
     assert torch.equal(Z[uncut], Zk[uncut])
@@ -957,6 +956,41 @@ def test_row_strips_keep_non_finite_values_with_their_neighbours():
     Sz = spmm_cpp.StripPlan(neg, 1.0, 256, min_tile_nnz=64)
     spmm_cpp.spmm_plan(neg, spmm_cpp.pad_rows(torch.from_numpy(Bz).to(dev)), Cz, 1.0, 1.0, spmm_cpp.StripHybridPlan(Sz, spmm_cpp.SegPlan(Sz.rest, 1)))
     assert bool(torch.signbit(Cz).all())                                   # -0.0 + (-a) * (+0.0) = -0.0, pads included
+
+
+def test_strict_switch_gives_every_row_the_oracle_bits(monkeypatch):
+    """DGNN_STRICT=1 (parity / debugging runs): no strips, tiles or bundles and no cut runs -- every row, hub rows included,
+    carries the CPU oracle's bits, and a non-finite feature stays with its neighbours."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(5)
+    n, m, F = 3000, 3000, 256
+    row, col, val = _rand_csr(rng, n, m, 300000, hub_rows=4)
+    col = np.where(rng.random(col.size) < 0.6, col % 120, col).astype(np.int32)
+    key = np.unique(row.astype(np.int64) * m + col)
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    val = rng.random(key.size, dtype=np.float32) - 0.3
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    B[17] = np.inf
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, np.zeros((n, F), dtype=np.float32), 1.0, 0.0)
+    blk = _gpu_block(row, col, val, n, m)
+    for k in ('DGNN_DENSE_MIN_NNZ', 'DGNN_STRIP_MIN_NNZ'):
+        monkeypatch.setenv(k, '1')
+    monkeypatch.setenv('DGNN_DENSE_MIN_DEG', '1')
+    monkeypatch.setenv('DGNN_STRIP_MIN_DEG', '1')
+    fast = spmm_cpp._plan_for(blk, F)
+    assert isinstance(fast, (spmm_cpp.StripHybridPlan, spmm_cpp.HybridPlan, spmm_cpp.BundlePlan))
+    monkeypatch.setenv('DGNN_STRICT', '1')
+    plan = spmm_cpp._plan_for(blk, F)
+    assert isinstance(plan, spmm_cpp.SegPlan) and plan.ncut == 0
+    dev = torch.device('cuda:0')
+    Cg = torch.full((n, F), float('nan'), device=dev)
+    spmm_cpp.spmm_plan(blk, spmm_cpp.pad_rows(torch.from_numpy(B).to(dev)), Cg, 1.0, 0.0, plan)
+    got = Cg.cpu().numpy()
+    assert np.array_equal(got, want, equal_nan=True)
+    touched = np.zeros(n, dtype=bool)
+    touched[row[col == 17]] = True
+    assert np.isfinite(got[~touched]).all() and touched.any()
 
 
 def test_dense_entry_point_rejects_bad_arguments():

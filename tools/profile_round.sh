@@ -25,11 +25,11 @@ echo "kernel trace done"
 
 DGNN_TUNE_GEMM=0 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$raw/fetch" -- \
     python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err" || exit 4
-python tools/pmc_summary.py "$raw/fetch" "_kernel<" | grep -A1 -E "spmm_(stage|bundle|hot|dense)_kernel" | grep -v "^--" > "$out/pmc_fetch_size.txt"
+python tools/pmc_summary.py "$raw/fetch" "_kernel" | grep -A1 -E "spmm_(stage|bundle|hot|dense|strip)_kernel" | grep -v "^--" > "$out/pmc_fetch_size.txt"
 echo "fetch pass done"
 
 DGNN_TUNE_GEMM=0 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$raw/write" -- \
     python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2 > "$out/pmc_write_bench.json" 2> "$out/pmc_write.err" || exit 5
-python tools/pmc_summary.py "$raw/write" "_kernel<" | grep -A1 -E "spmm_(stage|bundle|hot|dense)_kernel" | grep -v "^--" > "$out/pmc_write_size.txt"
+python tools/pmc_summary.py "$raw/write" "_kernel" | grep -A1 -E "spmm_(stage|bundle|hot|dense|strip)_kernel" | grep -v "^--" > "$out/pmc_write_size.txt"
 echo "write pass done"
 rm -rf "$raw"

@@ -26,8 +26,8 @@ for a, b in (('kernel_stats.csv', 'bench_kernel_stats.csv'), ('kernel_durations.
 def parse(p):
     out, name = {}, None
     for l in open(p):
-        if l.startswith('void'):
-            name = re.search(r'spmm_(?:stage|bundle|hot|dense)_kernel<[^>]*>', l).group(0)
+        if not l[0].isspace():
+            name = re.search(r'spmm_(?:stage|bundle|hot|dense|strip)_kernel(?:<[^>]*>)?', l).group(0)
         else:
             m = re.search(r'n=\s*(\d+) mean=([\d.e+]+) sum=([\d.e+]+)', l)
             if m:
@@ -47,6 +47,6 @@ d = dict(hbm_bytes_per_launch=int((fetch + write) / n), launches_in_pass=n, fetc
          command='DGNN_TUNE_GEMM=0 python bench.py --no-alt --cpu-budget 0 --steps 3 --warmup 2',
          how="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `DGNN_TUNE_GEMM=0 python bench.py --cpu-budget 0 "
              "--steps 3 --warmup 2` (library-default GEMMs there; the SpMM launches are the same) (KiB per dispatch; FETCH_SIZE doubled for gfx950 per MI355X_MICROARCH.md), averaged "
-             "over all SpMM stage launches of the pass (spmm_dense_kernel, spmm_bundle_kernel and spmm_stage_kernel); counts L2-side fabric requests, Infinity-Cache hits included")
+             "over all SpMM stage launches of the pass (spmm_strip_kernel, spmm_dense_kernel, spmm_bundle_kernel and spmm_stage_kernel, whichever ran); counts L2-side fabric requests, Infinity-Cache hits included")
 json.dump(d, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
 print(json.dumps(d, indent=1))

@@ -710,6 +710,60 @@ def test_papers_shaped_rank_slab(F):
         torch.cuda.empty_cache()
 
 
+def test_papers_rank_slab_at_full_size():
+    """BASELINE config 5 at the size it names: rank 3 of 8 of the ogbn-papers100M-shaped R-MAT graph (111 M nodes, 1.6 G
+    entries), built on this GPU alone by synthetic.make_partition -- 13.9 M rows, ~200 M nonzeros, gathered operand
+    111 M x 128 floats (57 GB) -- through the checks of test_papers_shaped_rank_slab: slab form = block form bit for bit,
+    the row kernel's bits on every uncut row, the fp64 bound on a 16-column band at either end (the fp64 operand of all
+    128 columns would be 114 GB), run-to-run bits."""
+    import coo_graph
+    import spmm_cpp
+    from coo_graph import synthetic
+    from models import gcn
+    dev = torch.device('cuda:0')
+    _shape_blocks.clear()
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info()[0] < 200 * 2**30:
+        pytest.skip('needs ~150 GB of free HBM')
+    P, rank, F = 8, 3, 128
+    n = synthetic.SHAPES['papers'][0]
+    part = synthetic.make_partition('papers', rank, P, seed=0, device=dev)
+    pg = coo_graph.Parted_COO_Graph('papers', rank, P, device=dev, attr_dict=part)
+    del part
+    s = pg.local_num_nodes
+    assert s == (n + P - 1) // P and s > 13_800_000 and pg.adj_parts.slab.size(1) == s * P
+    nnz = pg.adj_parts.slab._nnz()
+    assert nnz > 150_000_000
+    H = torch.rand(s * P, F, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    z_slab = torch.full((s, F), float('nan'), device=dev)
+    gcn.spmm(pg.adj_parts.slab, H, z_slab, fresh=True)
+    z_blocks = torch.full((s, F), float('nan'), device=dev)
+    for src in range(P):
+        gcn.spmm(pg.adj_parts[src], H[src * s:(src + 1) * s], z_blocks, fresh=(src == 0))
+    slab = gcn._csr_block(pg.adj_parts.slab)
+    deg = slab.rowptr[1:] - slab.rowptr[:-1]
+    short = deg <= 128
+    assert int(short.sum()) > 0.95 * s and int((deg == 1).sum()) > 0
+    zk = torch.zeros(s, F, device=dev)
+    spmm_cpp.spmm_csr(slab, H, zk, 1.0, 0.0)
+    assert torch.equal(z_slab[short], zk[short]) and torch.equal(z_blocks[short], zk[short])
+    del zk
+    z2 = torch.full((s, F), float('nan'), device=dev)
+    gcn.spmm(pg.adj_parts.slab, H, z2, fresh=True)
+    assert torch.equal(z2, z_slab)
+    del z2
+    A = pg.adj_parts.slab.coalesce()
+    A64 = torch.sparse_coo_tensor(A.indices(), A.values().double(), A.shape)
+    for c0 in (0, F - 16):
+        exact = torch.sparse.mm(A64, H[:, c0:c0 + 16].double())
+        for got in (z_slab, z_blocks):
+            assert ((got[:, c0:c0 + 16].double() - exact).abs() <= 1e-5 * exact).all()
+        del exact
+    del A64, A, H, pg, slab
+    _shape_blocks.clear()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('n,m,nnz,hubs,F,nstage,piece,hot,alpha,beta', [
     (3000, 5000, 200000, 3, 256, 2, 512, 256, 1.0, 1.0), (2500, 4000, 150000, 2, 100, 3, 256, 512, 0.5, 2.0),
     (1500, 9000, 120000, 2, 602, 4, 1024, 256, 1.0, 0.0), (4000, 1200, 90000, 0, 41, 1, 4096, 512, 1.0, 1.0),

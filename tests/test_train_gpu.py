@@ -330,3 +330,71 @@ def test_default_training_run_reproduces_its_bits(env, golden_dir):
         runs.append(dist_train.train(pg, env, total_epoch=4))
     if os.environ.get('DGNN_TUNE_GEMM', '0') == '0':
         assert runs[0] == runs[1], runs
+
+
+def test_transform_first_layer_against_the_reference_vectors(env, golden_dir, monkeypatch):
+    """Opt-in DGNN_TRANSFORM_FIRST=1 (A_hat (H W) in place of gcn.py:39-41's (A_hat H) W) on the GPU at
+    P = 1: layer output and both gradients against the reference's own layer_out / layer_grad_* within north_star's 1e-5
+    (relative to the largest entry), and the aggregation really ran at the narrower width."""
+    import coo_graph
+    from models import gcn
+    import spmm_cpp
+    dev = env.device
+    monkeypatch.setenv('DGNN_TRANSFORM_FIRST', '1')
+    for name in ('tiny', 'ragged'):
+        g = np.load(os.path.join(golden_dir, f'{name}_graph.npz'))
+        w = np.load(os.path.join(golden_dir, f'{name}_P1.npz'))
+        full = coo_graph.COO_Graph(name, attr_dict=_raw(g, 'cpu'))
+        pg = coo_graph.Parted_COO_Graph(name, 0, 1, device=dev, attr_dict=full.partition(1, save=False)[0])
+        X = torch.from_numpy(w['r0_features']).to(dev).requires_grad_(True)
+        W = torch.from_numpy(w['r0_layer_W']).to(dev).requires_grad_(True)
+        assert W.size(1) < X.size(1)                                     # the rule that turns the order round
+        widths = []
+        real = gcn.broadcast
+        monkeypatch.setattr(gcn, 'broadcast', lambda parts, feat, tag, **kw: (widths.append((tag, feat.size(1))), real(parts, feat, tag, **kw))[1])
+        y = gcn.DistGCNLayer.apply(X, W, pg.adj_parts, 'L1')
+        y.backward(torch.from_numpy(w['r0_layer_grad_out']).to(dev))
+        monkeypatch.setattr(gcn, 'broadcast', real)
+        assert widths[0] == ('ForwardL1T', W.size(1)) and widths[1][1] == W.size(1), widths
+        rel = lambda got, want: float(np.abs(got.detach().cpu().numpy() - want).max() / np.abs(want).max())
+        assert rel(y, w['r0_layer_out']) <= 1e-5
+        assert rel(X.grad, w['r0_layer_grad_features']) <= 1e-5
+        assert rel(W.grad, w['r0_layer_grad_weight']) <= 1e-5
+
+
+def test_transform_first_at_full_reddit_size(env, monkeypatch):
+    """The alt leg of the bench line (transform_first_ms_per_step) is this arithmetic: layer 1 of the Reddit-shape model at
+    FULL size, A_hat (X W) with X [232965 x 602], W [602 x 256], against the fp64 product element by element (bound: 1e-5 of the sum of
+    the terms' magnitudes, A_hat (|X| |W|) -- the features have both signs), its weight gradient against fp64 within 1e-5 of the largest entry, and the default order
+    beside it on the same inputs."""
+    import coo_graph
+    from coo_graph import synthetic
+    from models import gcn
+    dev = env.device
+    torch.cuda.empty_cache()
+    part = synthetic.make_partition('reddit', 0, 1, seed=0, device=dev)
+    pg = coo_graph.Parted_COO_Graph('reddit', 0, 1, device=dev, attr_dict=part)
+    n = pg.local_num_nodes
+    assert n == 232965 and pg.adj_parts[0]._nnz() > 114_000_000
+    gen = torch.Generator(device=dev).manual_seed(11)
+    X = pg.features
+    W = torch.rand(602, 256, device=dev, generator=gen).requires_grad_(True)
+    G = torch.rand(n, 256, device=dev, generator=gen) * 1e-3
+    A = pg.adj_parts[0].coalesce()
+    A64 = torch.sparse_coo_tensor(A.indices(), A.values().double(), A.shape)
+    exact = torch.sparse.mm(A64, X.double() @ W.detach().double())
+    mag = torch.sparse.mm(A64, X.double().abs() @ W.detach().double().abs())
+    exact_gw = X.double().t() @ torch.sparse.mm(A64, G.double())       # gcn.py:47-50 (A_hat symmetric)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('DGNN_TRANSFORM_FIRST', flag)
+        W.grad = None
+        y = gcn.DistGCNLayer.apply(X, W, pg.adj_parts, 'L1')
+        y.backward(G)
+        assert ((y.detach().double() - exact).abs() <= 1e-5 * mag).all(), flag
+        assert float((W.grad.double() - exact_gw).abs().max() / exact_gw.abs().max()) <= 1e-5, flag
+        outs[flag] = y.detach()
+    assert not torch.equal(outs['0'], outs['1'])                         # a different association, as documented
+    assert float(((outs['0'] - outs['1']).abs() / mag.float()).max()) <= 1e-5
+    del exact, mag, exact_gw, A64, pg, part
+    torch.cuda.empty_cache()

@@ -240,6 +240,27 @@ def scenario_adaptive_oracle(env, rank, world, gold_dir, name, num_layers):
     return adaptive_vs_oracle(env, rank, world, gold_dir, name, num_layers, True)
 
 
+def scenario_transform_first(env, rank, world, gold_dir, name):
+    """Opt-in A_hat (H W) at P > 1 with the HIP kernels: the reference's layer_out and both gradients."""
+    import coo_graph
+    from models import gcn
+    dev = env.device
+    gold = np.load(os.path.join(gold_dir, f'{name}_graph.npz'))
+    w = np.load(os.path.join(gold_dir, f'{name}_P{world}.npz'))
+    full = coo_graph.COO_Graph(name, attr_dict=_raw(gold, 'cpu'))
+    g = coo_graph.Parted_COO_Graph(name, rank, world, device=dev, attr_dict=full.partition(world, save=False)[rank])
+    os.environ['DGNN_TRANSFORM_FIRST'] = '1'
+    try:
+        X = torch.from_numpy(w[f'r{rank}_features']).to(dev).requires_grad_(True)
+        W = torch.from_numpy(w[f'r{rank}_layer_W']).to(dev).requires_grad_(True)
+        y = gcn.DistGCNLayer.apply(X, W, g.adj_parts, 'L1')
+        y.backward(torch.from_numpy(w[f'r{rank}_layer_grad_out']).to(dev))
+    finally:
+        os.environ['DGNN_TRANSFORM_FIRST'] = '0'
+    return dict(out=_rel(y, w[f'r{rank}_layer_out']), gf=_rel(X.grad, w[f'r{rank}_layer_grad_features']),
+                gw=_rel(W.grad, w[f'r{rank}_layer_grad_weight']), narrower=bool(W.size(1) < X.size(1)))
+
+
 def _worker(rank, world, port, scenario, args, log_dir, q):
     try:
         for p in (ROOT, os.path.join(ROOT, 'dist-gnn_amd')):
@@ -358,3 +379,10 @@ def test_adaptive_policy_matches_its_oracle(world, name, num_layers, tmp_path):
         assert res['z1_exact'], (r, res)                                 # constant input: the bits of the oracle's chain
         assert set(res['z_err']) == {f'layer{i + 1}' for i in range(num_layers)}
         assert max(res['z_err'].values()) <= 1e-5 and res['loss_err'] <= 1e-5, (r, res)
+
+
+@pytest.mark.parametrize('world,name', [(2, 'tiny'), (3, 'ragged')])
+def test_transform_first_matches_the_reference_layer(world, name, tmp_path):
+    out = _run(world, 'transform_first', str(tmp_path), name)
+    for r, res in out.items():
+        assert res['narrower'] and res['out'] <= 1e-5 and res['gf'] <= 1e-5 and res['gw'] <= 1e-5, (r, res)

@@ -223,10 +223,18 @@ def main():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode)
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1 and os.environ.get('DGNN_SUPERVISED') != '1' and os.environ.get('DGNN_SUPERVISE', '1') == '1':
+        # A rank as the launcher (this file's own or the driver's torch.distributed.run) started it: it stays off the GPU
+        # and runs the real rank as a child process, so that an exchange form that hangs on its first RCCL run costs
+        # one restart of fresh rank processes without that form (DGNN_AUTO_EXCLUDE) instead of the job
+        # (dist_utils/supervise.py; per-trial deadline DGNN_FORM_DEADLINE_S, default 180 s). DGNN_SUPERVISE=0: run directly.
+        faulthandler.cancel_dump_traceback_later()
+        from dist_utils import supervise
+        raise SystemExit(supervise.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -382,7 +390,13 @@ def main():
                     # a lower bound on the link rate, since only the exposed wait is in the denominator
                     per_link_GBps_if_fully_exposed=round(wire / max(exposed, 1e-6) / 1e6 / max(world - 1, 1), 1),
                     exposed_share_of_step=round(exposed / max(elapsed / args.steps * 1e3, 1e-9), 3),
-                    xgmi_link_peak_GBps=153.0, needed_rows_fraction=(round(moved / full, 4) if full else None))
+                    xgmi_link_peak_GBps=153.0, needed_rows_fraction=(round(moved / full, 4) if full else None),
+                    # what 'auto' measured when it chose (slowest rank's ms, best of two; first_use = the form's first
+                    # run, set-up excluded) and what the supervising launcher had to drop after a hang
+                    forms_ms={f'{k[0]}[{k[1]}x{k[2]}]': {f: round(t * 1e3, 3) for f, t in v[1].items()} for k, v in sorted(pipe.choice.items())},
+                    first_use_ms={f'{k[0]}[{k[1]}x{k[2]}]': {f: round(t * 1e3, 1) for f, t in v.items()} for k, v in sorted(pipe.first_use.items())},
+                    excluded_forms=sorted(f for f in os.environ.get('DGNN_AUTO_EXCLUDE', '').split(',') if f),
+                    attempt=int(os.environ.get('DGNN_ATTEMPT', 0)))
     # Beside the headline (never part of it): the same epochs with the opt-in A_hat (H W) ordering, in which a
     # layer with F_out < F_in aggregates at the narrower width (re-associated fp32, <= 1e-5).
     alt = None

@@ -7,5 +7,6 @@ from .timer import DistTimer
 from .logger import DistLogger
 from .gemm import tune_gemms
 from . import gemm
+from . import supervise
 
 __all__ = ['DistEnv', 'DistTimer', 'DistLogger', 'tune_gemms', 'gemm']

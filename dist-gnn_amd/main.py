@@ -45,6 +45,11 @@ if __name__ == '__main__':
     args = parse_args()
     if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:      # launched by torchrun
         args.nprocs = int(os.environ['WORLD_SIZE'])
+        if args.nprocs > 1 and os.environ.get('DGNN_SUPERVISED') != '1' and os.environ.get('DGNN_SUPERVISE', '1') == '1':
+            # stay off the GPU and run the real rank as a child: an exchange form that hangs in 'auto' then costs one
+            # restart of fresh rank processes without it, not the job (dist_utils/supervise.py; DGNN_SUPERVISE=0: direct)
+            import sys
+            raise SystemExit(dist_utils.supervise.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
         process_wrapper(int(os.environ['RANK']), args, dist_train.main)
     else:
         torch.multiprocessing.spawn(process_wrapper, (args, dist_train.main), args.nprocs)

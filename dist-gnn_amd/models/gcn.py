@@ -64,25 +64,37 @@ class NeededRows:
       K[dst][src]    row counts, known to every rank (sizes of every message)
     """
 
-    def __init__(self, adj_parts, group):
+    def __init__(self, adj_parts, group, local=None):
         env = DistEnv.env
         P, rank = env.world_size, env.rank
         if dist.get_world_size(group) != P or len(adj_parts) != P:
             raise RuntimeError('NeededRows: only the 1D layout over the world group is supported')
         dev = adj_parts[0].device
-        self.cols, self.blocks = [], []
-        for src in range(P):
+        self.cols, self.blocks = local if local is not None else self._local(adj_parts, rank)
+        self._exchange(adj_parts, group, P, rank, dev)
+
+    @staticmethod
+    def _local(adj_parts, rank):
+        """The part of the set-up that needs no peer (and can fail on one rank alone): the distinct columns and the
+        renumbered block of every source."""
+        dev = adj_parts[0].device
+        cols_of, blocks = [], []
+        for src in range(len(adj_parts)):
             A = adj_parts[src] if adj_parts[src].is_coalesced() else adj_parts[src].coalesce()
             idx = A.indices()
             if src == rank:                       # the own block reads the local features in place
-                self.cols.append(torch.zeros(0, dtype=torch.long, device=dev))
-                self.blocks.append(A)
+                cols_of.append(torch.zeros(0, dtype=torch.long, device=dev))
+                blocks.append(A)
                 continue
             cols, inv = torch.unique(idx[1], sorted=True, return_inverse=True)
             blk = torch.sparse_coo_tensor(torch.stack([idx[0], inv]), A.values(), (A.size(0), max(int(cols.numel()), 1)),
                                           is_coalesced=True)   # still sorted by (row, column), no duplicates
-            self.cols.append(cols)
-            self.blocks.append(blk)
+            cols_of.append(cols)
+            blocks.append(blk)
+        return cols_of, blocks
+
+    def _exchange(self, adj_parts, group, P, rank, dev):
+        """Row counts (all-gather) and index lists (one all-to-all): collectives, every rank together."""
         counts = torch.tensor([c.numel() for c in self.cols], dtype=torch.long, device=dev)
         every = [torch.empty_like(counts) for _ in range(P)]
         dist.all_gather(every, counts, group=group)
@@ -150,10 +162,22 @@ class NeededRows:
         return got
 
     @staticmethod
+    def local_part(adj_parts, group):
+        """Build (and keep) this rank's own half of the set-up: no collective, so its failure can be voted on."""
+        if getattr(adj_parts, '_dgnn_needed', None) is None and getattr(adj_parts, '_dgnn_needed_local', None) is None:
+            local = NeededRows._local(adj_parts, DistEnv.env.rank)
+            try:
+                adj_parts._dgnn_needed_local = local
+            except AttributeError:
+                pass
+
+    @staticmethod
     def of(adj_parts, group):
         nr = getattr(adj_parts, '_dgnn_needed', None)
         if nr is None:
-            nr = NeededRows(adj_parts, group)
+            nr = NeededRows(adj_parts, group, local=getattr(adj_parts, '_dgnn_needed_local', None))
+            if hasattr(adj_parts, '_dgnn_needed_local'):
+                del adj_parts._dgnn_needed_local
             try:
                 adj_parts._dgnn_needed = nr
             except AttributeError:                # a plain list: rebuilt per call (tests only)
@@ -275,6 +299,7 @@ class StagePipeline:
         self.rows_full = 0             # ... and what whole blocks would have been
         self.fused_slab = os.environ.get('DGNN_FUSED_SLAB', '1') == '1'
         self.choice = {}               # (tag, rows, width, group size) -> (form, {form: seconds}) picked by 'auto'
+        self.first_use = {}            # same key -> {form: seconds of its first run, set-up excluded} (logs, bench line)
 
     def _buffers(self, shape, like, count, tag=''):
         key = (tuple(shape), like.dtype, like.device, tag)
@@ -583,14 +608,79 @@ class StagePipeline:
         self.rows_full += nr.block_rows * (P - 1)
         return z
 
+    def _prepare(self, form, adj_parts, feat, stages, group):
+        """Everything of a form that can fail on one rank alone: receive / gather / send buffers, the CSR blocks and
+        work plans of the matrices it multiplies at the widths it multiplies them, the compact row slab. NO collective
+        is posted here, so a rank that raises can still tell its peers in the vote that follows (_pick_form)."""
+        env = DistEnv.env
+        P, s, F = len(stages), feat.size(0), feat.size(1)
+        on_gpu = feat.is_cuda and _spmm_override is None
+        slab = getattr(adj_parts, 'slab', None) if self.fused_slab else None
+        fused = slab is not None and slab.size(1) == P * s and [src for src, _ in stages] == list(range(P))
+
+        def plans(mats, widths):
+            if on_gpu:
+                import spmm_cpp
+                for A in mats:
+                    for w in widths:
+                        spmm_cpp._plan_for(_csr_block(A), w)
+
+        def slabs(chunks):
+            step = (-(-F // chunks) + 31) // 32 * 32 if chunks > 1 else F
+            return [min(c0 + step, F) - c0 for c0 in range(0, F, step)]
+
+        if form == 'bcast':
+            self._buffers((s, self._wire_width(feat)), feat, min(self.inflight, max(P, 1)), 'recv')
+            plans([adj_parts[blk] for _, blk in stages], [F])
+        elif form == 'allgather':
+            self._buffers((P * s, self._wire_width(feat)), feat, 1, 'gather')
+            plans([slab] if fused else [adj_parts[blk] for _, blk in stages], [F])
+        elif form in ('agpipe', 'agpipe4'):
+            ws = slabs(4 if form == 'agpipe4' else 2)
+            for c, w in enumerate(ws):
+                ld = (w + 31) // 32 * 32 if on_gpu else w
+                self._buffers((s, ld), feat, 1, f'agp-own{c}')
+                self._buffers((P * s, ld), feat, 1, f'agp-gather{c}')
+            plans([slab] if fused else [adj_parts[blk] for _, blk in stages], sorted(set(ws)))
+        else:                                               # needed, needed_a2a, needed_a2a2
+            nr = NeededRows.of(adj_parts, group)            # built (with its set-up exchange) before the trials
+            ws = slabs(2 if form == 'needed_a2a2' else 1)
+            if form == 'needed':
+                plans([nr.blocks[src] if src != env.rank else adj_parts[blk] for src, blk in stages], [F])
+            elif self.fused_slab and [src for src, _ in stages] == list(range(P)):
+                plans([nr.compact_slab()[0]], sorted(set(ws)))
+            else:
+                plans([nr.blocks[src] if src != env.rank else adj_parts[blk] for src, blk in stages], sorted(set(ws)))
+
     def _pick_form(self, adj_parts, feat, stages, group, tag):
-        """'auto': time both forms once for this (tag, shape) and keep the faster one."""
+        """'auto': run and time every candidate form once for this (tag, shape) and keep the fastest.
+
+        What can go wrong with a form, and what happens then:
+          * its set-up raises on some rank (memory for a gather buffer, a plan)  -> _prepare runs WITHOUT collectives
+            and is followed by a MAX all-reduce vote: every rank drops the form, the job goes on;
+          * it raises after _prepare, i.e. possibly after posting a collective its peers are now waiting in -> fatal
+            (the communicator is out of step; a vote could itself hang): supervise.give_up names the form and the
+            rank leaves; under the supervising launcher (bench.py, dist_utils/supervise.py) fresh rank processes
+            start without the form, otherwise the exception is re-raised;
+          * it hangs -> the per-trial deadline (DGNN_FORM_DEADLINE_S, armed by the launcher) ends the rank the same way;
+          * it is slower than DGNN_AUTO_CAP_S on first use -> dropped by the vote.
+        DGNN_AUTO_EXCLUDE=form[,form] removes candidates ('bcast', the reference's own form and the fallback of all
+        others, cannot be excluded)."""
         key = (tag, feat.size(0), feat.size(1), len(stages))
         hit = self.choice.get(key)
         if hit is not None:
             return hit[0]
         import time
+        from dist_utils import supervise
         sent = self.transfers
+        log = DistEnv.env.logger.log
+        # the votes travel as host tensors under gloo (its CUDA path stages through the host anyway)
+        vote_dev = feat.device if dist.get_backend(group) == 'nccl' else 'cpu'
+
+        def vote(*xs):
+            v = torch.tensor(xs, dtype=torch.float64, device=vote_dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+            return [float(x) for x in v.tolist()]
 
         forms = ['bcast']
         if self._gather_fits(feat, len(stages)):            # the gathered matrix is P times a block: papers-sized
@@ -601,6 +691,23 @@ class StagePipeline:
             # it is a candidate only on request (DGNN_AUTO_P2P=1). The all-to-all forms are plain collectives.
             p2p = dist.get_backend(group) != 'nccl' or os.environ.get('DGNN_AUTO_P2P', '0') == '1'
             forms += (['needed'] if p2p else []) + ['needed_a2a'] + (['needed_a2a2'] if feat.size(1) >= 64 else [])
+        out = supervise.excluded()
+        if out:
+            forms = [f for f in forms if f == 'bcast' or f not in out]
+        if any(f.startswith('needed') for f in forms):
+            # the index lists are exchanged once, by all ranks together, and only if every rank built its own
+            # (NeededRows.local_part: no collective) -- vote first, exchange after
+            try:
+                NeededRows.local_part(adj_parts, group)
+                bad = 0.0
+            except Exception as e:                          # noqa: BLE001
+                log(f'pipeline auto {tag}: needed-rows set-up raised {type(e).__name__}: {e} -- forms dropped', rank=-1)
+                bad = 1.0
+            if vote(bad)[0]:
+                forms = [f for f in forms if not f.startswith('needed')]
+            else:
+                with supervise.deadline('needed_a2a'):
+                    NeededRows.of(adj_parts, group)
         moved = (self.rows_moved, self.rows_full)
 
         def once(form):
@@ -622,54 +729,61 @@ class StagePipeline:
                 torch.cuda.synchronize(feat.device)
             return time.perf_counter() - t0
 
-        # the vote travels as a host tensor under gloo (its CUDA path stages through the host anyway)
-        vote_dev = feat.device if dist.get_backend(group) == 'nccl' else 'cpu'
-        log = DistEnv.env.logger.log
-
-        def trial(form):
-            """One run of a form on every rank -> the slowest rank's seconds, or None when it raised on any rank
-            (every rank learns the outcome from one MAX all-reduce, so all drop the same forms). 'bcast' is the
-            reference's own form and the fallback of all others: its failure is the job's."""
-            try:
-                t, bad = once(form), 0.0
-            except Exception as e:                          # noqa: BLE001 -- whatever it is, the form is out
-                if form == 'bcast':
+        def trial(form, first=False):
+            """One run of a form on every rank -> the slowest rank's seconds; None when its set-up raised on any rank
+            (first use only; every rank learns it from one MAX all-reduce, so all drop the same forms)."""
+            with supervise.deadline(form):
+                if first:
+                    try:
+                        self._prepare(form, adj_parts, feat, stages, group)
+                        bad = 0.0
+                    except Exception as e:                  # noqa: BLE001 -- whatever it is, the form is out
+                        if form == 'bcast':                 # the reference's own form, everybody's fallback: the job's failure
+                            raise
+                        log(f'pipeline auto {tag}: set-up of form {form} raised {type(e).__name__}: {e} -- dropped', rank=-1)
+                        bad = 1.0
+                    if vote(bad)[0]:
+                        return None
+                try:
+                    t = once(form)
+                except Exception as e:                      # noqa: BLE001
+                    log(f'pipeline auto {tag}: form {form} raised {type(e).__name__}: {e} after its set-up -- the ranks '
+                        'may be out of step inside a collective: fatal', rank=-1)
+                    if form != 'bcast' and os.environ.get('DGNN_SUPERVISED') == '1':
+                        supervise.give_up(form, f'raised {type(e).__name__} after its set-up')
                     raise
-                log(f'pipeline auto {tag}: form {form} raised {type(e).__name__}: {e} -- dropped', rank=-1)
-                t, bad = 0.0, 1.0
-            v = torch.tensor([bad, t], dtype=torch.float64, device=vote_dev)
-            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
-            bad, t = (float(x) for x in v.tolist())
-            return None if bad else t
+                return vote(t)[0]
 
         cap = float(os.environ.get('DGNN_AUTO_CAP_S', 30.0))
-        times = {}
+        times, first_use = {}, {}
         with torch.no_grad():
             # line the ranks up first: the first epoch is also where each rank times its library GEMM candidates
             # (dist_utils.tune_gemms), seconds that differ from rank to rank and would otherwise be charged to the
             # first form tried (and could push it over the cap)
-            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=vote_dev), group=group)
+            vote(0.0)
             if feat.is_cuda:
                 torch.cuda.synchronize(feat.device)
             alive = []
             for f in forms:                                 # builds CSR blocks, plans and buffers: not timed
-                t = trial(f)
+                t = trial(f, first=True)
+                if t is not None:
+                    first_use[f] = t
                 if t is not None and (f == 'bcast' or t <= cap):
                     alive.append(f)
                 elif t is not None:
                     log(f'pipeline auto {tag}: form {f} took {t:.1f} s on first use (cap {cap:.0f} s) -- dropped', rank=0)
             for f in alive:
                 # best of two timed runs per form: one sample is at the mercy of whatever else the node is doing
-                ts = [trial(f), trial(f)]
-                if None not in ts:
-                    times[f] = min(ts)
+                times[f] = min(trial(f), trial(f))
         forms = [f for f in forms if f in times]
         form = min(forms, key=lambda f: (times[f], forms.index(f)))
         self.choice[key] = (form, times)
+        self.first_use[key] = first_use
         self.rows_moved, self.rows_full = moved
         self.transfers = sent                               # tuning traffic is not part of the count
         DistEnv.env.logger.log(f'pipeline auto {tag} [{feat.size(0)}x{feat.size(1)}] P={len(stages)}: '
-                               + ', '.join(f'{f} {times[f] * 1e3:.3f} ms' for f in forms) + f' -> {form}', rank=0)
+                               + ', '.join(f'{f} {times[f] * 1e3:.3f} ms' for f in forms) + f' -> {form}'
+                               + (f' (excluded: {",".join(sorted(out))})' if out else ''), rank=0)
         return form
 
     @staticmethod

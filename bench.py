@@ -441,7 +441,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "epoch_time_s": round(elapsed / args.steps, 6),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": f"synthetic (seeded R-MAT, {args.workload} shape, random-init torch.rand weights)",
+            "data": f"synthetic (seeded R-MAT, {args.workload} shape, random-init torch.rand weights)" + (
+                # the R-MAT caveat on the record line: the real ogbn-products has communities, R-MAT has none
+                "; R-MAT has no communities for `prepare_data.py --reorder auto` to recover (it leaves such a graph as it is). "
+                "Stored, not measured in this run (profiles/r02_reorder_planted.txt): a planted-partition graph of this "
+                "size and degree, F=256 SpMM: 24.6 ms as generated (scrambled ids), 9.0 ms after the cluster order + "
+                "row-bucket work order that the default data preparation now applies" if args.workload == 'products' else ""),
             "config": {"workload": f"{args.workload}-shape {layers}-layer {args.model}, hidden {args.hidden}, 1D row partition over {world} GPU(s)",
                        "nodes": n_nodes, "nnz": int(nnz_total), "feature_widths_aggregated": widths,
                        "pipeline": gcn_mod.pipeline().describe(), "cache_input": bool(args.cache_input), "transport": 'rccl' if args.backend == 'nccl' else 'gloo (rehearsal, not a result)', "transform_first": bool(args.transform_first),

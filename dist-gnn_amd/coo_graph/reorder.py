@@ -111,6 +111,37 @@ def cluster_order(edge_index, n, rounds=8):
 
 ORDERS = {'bfs': bfs_order, 'degree': degree_order, 'cluster': cluster_order}
 
+ROW_BUCKET = 4096          # = spmm_cpp.ROW_BUCKET: the granularity at which the SpMM plans test a block for locality
+
+
+def locality_share(edge_index, n, bucket=ROW_BUCKET):
+    """The measure the SpMM plans use to switch to the row-bucket order (spmm_cpp.locality_share), on an edge list:
+    share of the (symmetrised) edges that sit, for their bucket of `bucket` consecutive rows, in that bucket's most
+    referenced bucket of consecutive columns. ~1 / buckets for a scrambled graph, near 1 for a clustered one."""
+    ei = edge_index.long()
+    if ei.size(1) == 0:
+        return 0.0
+    nb = -(-n // bucket)
+    rb = torch.cat([ei[0], ei[1]]) // bucket
+    cb = torch.cat([ei[1], ei[0]]) // bucket
+    cnt = torch.bincount(rb * nb + cb, minlength=nb * nb)
+    return float(cnt.view(nb, nb).max(dim=1).values.sum().item()) / (2 * ei.size(1))
+
+
+def auto_reorder(d, threshold=0.5):
+    """'auto': take the cluster order if the relabelled graph is local enough for the row-bucket SpMM order to engage
+    (locality_share >= threshold, the plans' own test) and more local than it was; else leave the dataset as it is.
+    Returns (dataset, report dict). R-MAT-like graphs have nothing to recover and come back unchanged."""
+    n = d['num_nodes']
+    before = locality_share(d['edge_index'], n)
+    if before >= threshold:
+        return d, dict(order='none', before=before, after=before, why='local enough as it is')
+    out = relabel(d, cluster_order(d['edge_index'], n))
+    after = locality_share(out['edge_index'], n)
+    if after >= threshold and after > before:
+        return out, dict(order='cluster', before=before, after=after, why='row-bucket order will engage')
+    return d, dict(order='none', before=before, after=after, why='clustering recovers no locality (below %.2f)' % threshold)
+
 
 def reorder_dataset(d, how):
     if how not in ORDERS:

@@ -1771,7 +1771,10 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
 int dgnn_noalloc_limits(int64_t* scratch_bytes) {
   if (!scratch_bytes) return fail(DGNN_E_BADARG, "noalloc_limits: null pointer%s", "");
   *scratch_bytes = (int64_t)NOALLOC_SCRATCH_BYTES;
-  return DGNN_OK;
+  // the set-up of the current device (hipGetSymbolAddress: not a stream operation) happens here too, so that a caller
+  // who asks for the limits first -- outside any graph capture -- never pays it inside one
+  unsigned char* base = nullptr;
+  return noalloc_scratch(&base);
 }
 
 int dgnn_noalloc_scratch_needed(int32_t n, int32_t m, int64_t nnz, int64_t ldb, int64_t* bytes) {
@@ -1788,6 +1791,8 @@ int dgnn_spmm_coo_noalloc_f32(const int32_t* row, const int32_t* col, const floa
   if (n < 0 || m < 0 || F < 0 || nnz < 0 || nnz > 0x7fffffffLL)
     return fail(DGNN_E_BADARG, "spmm_coo_noalloc: bad sizes%s (nnz=%lld)", "", nnz);
   if (n == 0 || F == 0) return DGNN_OK;
+  if (!C || ldc < F || !B || (nnz > 0 && (!row || !col || !val)))
+    return fail(DGNN_E_BADARG, "spmm_coo_noalloc: null pointer or ldc < F%s", "");
   if (ldb < F || ldb % 4 != 0 || !aligned(B, 16))
     return fail(DGNN_E_BADARG, "spmm_coo_noalloc: B needs ldb >= F, ldb %% 4 == 0 and a 16-byte aligned base (dgnn_pad_rows_f32)%s", "");
   int64_t need = 0;

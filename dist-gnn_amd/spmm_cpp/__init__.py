@@ -209,6 +209,22 @@ class CsrBlock:
         self.rowptr, self.col, self.val = rowptr, col, val
         self.nnz = val.numel()
         self.device = val.device
+        self._distinct = None
+
+    def require_distinct(self, who):
+        """The tile / bundle / strip builders scatter one value per (row, column) into their lists: an entry that
+        occurs twice would silently lose one of its values. Blocks from a coalesced tensor (from_coo) are known to be
+        fine; a hand-built block is checked once."""
+        if self._distinct is None:
+            if self.nnz > 1:
+                rp = self.rowptr.long()
+                rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), rp[1:] - rp[:-1])
+                self._distinct = int(torch.unique(rows * self.m + self.col.long()).numel()) == self.nnz
+            else:
+                self._distinct = True
+        if not self._distinct:
+            raise RuntimeError(f'{who}: the block lists some (row, column) more than once; coalesce it first '
+                               '(CsrBlock.from_coo takes a coalesced tensor)')
 
     @classmethod
     def from_coo(cls, A):
@@ -232,7 +248,9 @@ class CsrBlock:
             _check(_lib.dgnn_idx_i64_to_i32(idx[0].data_ptr(), nnz, row32.data_ptr(), s), 'idx_i64_to_i32')
             _check(_lib.dgnn_idx_i64_to_i32(idx[1].data_ptr(), nnz, col32.data_ptr(), s), 'idx_i64_to_i32')
             _check(_lib.dgnn_coo2csr_i32(row32.data_ptr(), nnz, n, rowptr.data_ptr(), s), 'coo2csr')
-        return cls(n, m, rowptr, col32, val.contiguous())
+        blk = cls(n, m, rowptr, col32, val.contiguous())
+        blk._distinct = True                                # coalesced: every (row, column) once
+        return blk
 
 
 def spmm_csr(A, B, C, alpha=1.0, beta=1.0):
@@ -789,6 +807,7 @@ class BundlePlan:
     def __init__(self, A, nstage=1, R=4, piece_len=None):
         if R not in (2, 4, 6, 8):
             raise ValueError('R must be 2, 4, 6 or 8')
+        A.require_distinct('BundlePlan')
         dev = A.device
         n, m, nnz = A.n, A.m, A.nnz
         nstage = max(1, int(nstage))
@@ -912,6 +931,7 @@ class DensePlan:
 
     def __init__(self, A, min_count=None, min_cols=None, piece_len=None, keep_mask=False):
         TR = DENSE_TR
+        A.require_distinct('DensePlan')
         dev = A.device
         n, m, nnz = A.n, A.m, A.nnz
         if min_count is None:
@@ -1102,6 +1122,7 @@ class StripPlan:
     def __init__(self, A, max_ratio=None, piece_strips=None, min_tile_nnz=None, block_target=None):
         R, NW, WMAX, LINE = STRIP_R, STRIP_NW, STRIP_W, STRIP_LINE
         RW = R // NW
+        A.require_distinct('StripPlan')
         dev = A.device
         n, m, nnz = A.n, A.m, A.nnz
         if max_ratio is None:

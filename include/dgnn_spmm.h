@@ -359,6 +359,13 @@ int dgnn_spmm_coo_aligned_f32(const int32_t* row, const int32_t* col, const floa
  *   sharing   all calls on one GPU use that GPU's one array: calls that overlap in time on one GPU (two
  *             streams, two threads, a graph replay next to an eager call) RACE. Serialise them.
  *   B         ldb >= F, ldb % 4 == 0, 16-byte aligned base, as for dgnn_spmm_coo_aligned_f32
+ *   set-up    the first call on a device looks the array's address up (hipGetSymbolAddress: NOT a stream operation,
+ *             it may load the code object). It must happen OUTSIDE a graph capture: call dgnn_noalloc_limits() -- which
+ *             does the same look-up for the current device -- or one eager dgnn_spmm_coo_noalloc_f32 on every device
+ *             first. After that a call only enqueues kernels on `stream` and can be captured and replayed
+ *             (tests/test_zzz_no_alloc.py::test_noalloc_entry_point_under_graph_capture).
+ *   cost      the array is part of the code object: EVERY process that loads the library holds 64 MiB on every GPU it
+ *             touches, whether or not it ever calls this entry point.
  */
 #define DGNN_NOALLOC_SCRATCH_BYTES (64u << 20)
 int dgnn_noalloc_limits(int64_t* scratch_bytes);

@@ -117,3 +117,22 @@ def test_locality_share_tells_a_clustered_graph_from_a_scrambled_one():
     assert spmm_cpp.locality_share(_cpu_block(new[ei], n)) > 0.6
     d = synthetic.make_dataset('reddit', seed=0, device='cpu', num_nodes=n, num_edges=1500000, with_features=False)
     assert spmm_cpp.locality_share(_cpu_block(d['edge_index'], n)) < 0.3
+
+
+def test_auto_reorder_keeps_the_cluster_order_only_where_it_pays():
+    """prepare_data.py's default (--reorder auto): a scrambled graph WITH communities comes back in the cluster order and
+    passes the plans' own locality test; R-MAT (nothing to recover) and an already local graph come back unchanged."""
+    from coo_graph import reorder, synthetic
+    n = 40000
+    keys = synthetic.planted_undirected(n, 400000, community=2048, seed=1)
+    ei = torch.stack([keys // n, keys % n])
+    d = dict(edge_index=ei, num_nodes=n, labels=torch.arange(n))
+    out, rep = reorder.auto_reorder(d)
+    assert rep['order'] == 'cluster' and rep['before'] < 0.3 and rep['after'] >= 0.5
+    assert torch.equal(out['labels'], out['node_order'])                # per-node data travelled with the nodes
+    assert abs(reorder.locality_share(out['edge_index'], n) - rep['after']) < 1e-12
+    again, rep2 = reorder.auto_reorder({k: v for k, v in out.items() if k != 'node_order'})
+    assert rep2['order'] == 'none' and again['edge_index'] is out['edge_index']
+    r = synthetic.make_dataset('reddit', seed=0, device='cpu', num_nodes=n, num_edges=600000, with_features=False)
+    same, rep3 = reorder.auto_reorder(dict(edge_index=r['edge_index'], num_nodes=n))
+    assert rep3['order'] == 'none' and rep3['after'] < 0.5 and 'node_order' not in same

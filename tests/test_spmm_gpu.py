@@ -1104,3 +1104,21 @@ def test_row_bucketed_order_is_chosen_for_blocks_with_locality_and_changes_no_bi
         uncut = plan.uncut_rows()
         assert int(uncut.sum()) > 0.99 * n and torch.equal(Z[uncut], Zk[uncut])
         assert ((Z - Zk).abs() <= 1e-5 * Zk.abs()).all()
+
+
+def test_plan_builders_refuse_a_block_with_repeated_entries():
+    """Tiles, bundles and strips store ONE value per (row, column): a hand-built block that lists an entry twice (never a
+    coalesced one) would silently lose a value -- the builders refuse it; the run plans and the row kernel add both."""
+    import spmm_cpp
+    dev = torch.device('cuda:0')
+    rowptr = torch.tensor([0, 3, 4], dtype=torch.int32, device=dev)
+    col = torch.tensor([1, 1, 2, 0], dtype=torch.int32, device=dev)
+    val = torch.tensor([1.0, 2.0, 3.0, 4.0], device=dev)
+    A = spmm_cpp.CsrBlock(2, 3, rowptr, col, val)
+    for build in (lambda: spmm_cpp.BundlePlan(A), lambda: spmm_cpp.DensePlan(A), lambda: spmm_cpp.StripPlan(A)):
+        with pytest.raises(RuntimeError, match='more than once'):
+            build()
+    B = spmm_cpp.pad_rows(torch.eye(3, device=dev))
+    C = torch.zeros(2, 3, device=dev)
+    spmm_cpp.spmm_csr(A, B[:, :3], C, 1.0, 0.0)
+    assert C.tolist() == [[0.0, 3.0, 3.0], [4.0, 0.0, 0.0]]

@@ -81,3 +81,31 @@ def test_noalloc_entry_point_rejects_what_does_not_fit():
     rc = lib.dgnn_spmm_coo_noalloc_f32(z.data_ptr(), z.data_ptr(), f.data_ptr(), 4, 4, 2, f.data_ptr() + 4, 30, f.data_ptr(), 32, 8,
                                        1.0, 1.0, None)
     assert rc == 1                                                     # misaligned / unpadded B
+
+
+def test_noalloc_entry_point_under_graph_capture():
+    """What the entry point is for: after the per-device set-up (dgnn_noalloc_limits, outside the capture) a call only
+    enqueues kernels on the stream it is given -- captured into a HIP graph and replayed on new operand VALUES (same
+    buffers), it gives the bits of the eager workspace entry point each time."""
+    import spmm_cpp
+    lib = spmm_cpp.lib
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    cap = ctypes.c_int64()
+    assert lib.dgnn_noalloc_limits(ctypes.byref(cap)) == 0           # set-up of this device, outside the capture
+    n, m, nnz, F, hub = 5000, 7000, 200000, 100, 30000               # long rows: pieces, partial rows, merge
+    row, col, val, B, C0, ld = _block(n, m, nnz, F, 77, dev, hub)
+    out = C0.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rc = lib.dgnn_spmm_coo_noalloc_f32(row.data_ptr(), col.data_ptr(), val.data_ptr(), n, m, val.numel(), B.data_ptr(), ld,
+                                           out.data_ptr(), out.stride(0), F, 1.0, 0.5, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.dgnn_last_error()
+    for scale in (1.0, 3.0):
+        B.mul_(scale)
+        out.copy_(C0)
+        want = C0.clone()
+        _aligned(lib, spmm_cpp, row, col, val, n, m, B, ld, want, F, 1.0, 0.5)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (scale, (out - want).abs().max().item())

@@ -1126,7 +1126,7 @@ class StripPlan:
         dev = A.device
         n, m, nnz = A.n, A.m, A.nnz
         if max_ratio is None:
-            max_ratio = float(os.environ.get('DGNN_STRIP_MAX_RATIO', 0.8))
+            max_ratio = float(os.environ.get('DGNN_STRIP_MAX_RATIO', 0.7))
         if piece_strips is None:
             piece_strips = int(os.environ.get('DGNN_STRIP_PIECE', 512))
         if min_tile_nnz is None:

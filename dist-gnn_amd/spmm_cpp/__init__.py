@@ -20,6 +20,7 @@ Differences from the reference, on purpose:
     re-marshalling int64 indices on every call (gcn.py:11).
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -1128,14 +1129,14 @@ class StripPlan:
         if max_ratio is None:
             max_ratio = float(os.environ.get('DGNN_STRIP_MAX_RATIO', 0.7))
         if piece_strips is None:
-            piece_strips = int(os.environ.get('DGNN_STRIP_PIECE', 512))
+            piece_strips = int(os.environ.get('DGNN_STRIP_PIECE', 0))      # 0: by the number of strips, below
         if min_tile_nnz is None:
             min_tile_nnz = int(os.environ.get('DGNN_STRIP_MIN_TILE_NNZ', 1024))
         if block_target is None:
             block_target = float(os.environ.get('DGNN_STRIP_BLOCK', 52))
-        if piece_strips < 1:
-            raise ValueError('piece_strips must be positive')
-        self.max_ratio, self.piece_strips = float(max_ratio), int(piece_strips)
+        if piece_strips < 0:
+            raise ValueError('piece_strips must not be negative')
+        self.max_ratio = float(max_ratio)
         i64 = dict(dtype=torch.long, device=dev)
         rp = A.rowptr.long()
         deg = rp[1:] - rp[:-1]
@@ -1185,6 +1186,15 @@ class StripPlan:
         del e_uslot, e_i, w_e
         # strips and pieces of every tile
         nstrip_t = (usz_s + w_t - 1) // w_t
+        # Piece length: one workgroup walks one piece per feature chunk, so a launch wants several pieces per CU whatever
+        # the block's size -- the row slab of one of 8 ranks has an eighth of the tiles but hub tiles as long as the whole
+        # graph's. Rule: total strips / 384, to the nearest power of two in 32 .. 512 (Reddit shape: 512 for the whole block,
+        # 128 for a rank's slab at 8 ranks, where 512 costs 3x at F = 256: profiles/r03_slab_piece_sweep.txt).
+        self.nstrips = int(nstrip_t.sum().item())
+        if not piece_strips:
+            want = max(self.nstrips / 384.0, 1.0)
+            piece_strips = min(512, max(32, 1 << int(round(math.log2(want)))))
+        self.piece_strips = int(piece_strips)
         np_t = (nstrip_t + self.piece_strips - 1) // self.piece_strips
         spp_t = torch.where(np_t > 0, (nstrip_t + np_t.clamp(min=1) - 1) // np_t.clamp(min=1), torch.zeros_like(np_t))
         np_t = torch.where(spp_t > 0, (nstrip_t + spp_t.clamp(min=1) - 1) // spp_t.clamp(min=1), torch.zeros_like(np_t))

@@ -90,7 +90,10 @@ def main():
         z1.zero_(); per_block(); z2.zero_(); fused()
         same = torch.equal(z1, z2)
         tb, tf = timed(per_block), timed(fused)
-        print(f'F={F:4d}  {P} block SpMMs {tb:7.3f} ms   one slab SpMM {tf:7.3f} ms   same bits: {same}   '
+        pl = spmm_cpp._plan_for(A_slab, F)
+        how = (f'strips: {pl.strip.nstrips} strips, {pl.strip.npiece} pieces of <= {pl.strip.piece_strips}, share {pl.strip.share:.2f}'
+               if isinstance(pl, spmm_cpp.StripHybridPlan) else type(pl).__name__)
+        print(f'F={F:4d}  {P} block SpMMs {tb:7.3f} ms   one slab SpMM {tf:7.3f} ms [{how}]   same bits: {same}   '
               f'(gathered H: {H.numel() * 4 / 2**30:.1f} GiB)', flush=True)
         # the needed-rows forms: every remote block against only the rows it references (columns renumbered), as P
         # compact products or as ONE product of the compact row slab (NeededRows.compact_slab builds the same matrix)

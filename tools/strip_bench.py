@@ -22,7 +22,7 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0)
     ap.add_argument('--F', default='602,256')
     ap.add_argument('--max-ratio', default='0.5')
-    ap.add_argument('--piece', default='256')
+    ap.add_argument('--piece', default='0', help='strips per piece (0 = the plan builder\'s rule)')
     ap.add_argument('--block', default='26', help='entries a wave should find in one strip (sets the strip width per tile)')
     ap.add_argument('--variants', default='', help='library debug variants to time the strip kernel with (502: no fills)')
     ap.add_argument('--iters', type=int, default=5)

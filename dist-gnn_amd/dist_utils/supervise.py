@@ -66,11 +66,17 @@ def deadline(form):
         return
     t = threading.Timer(s, give_up, (form, f'no answer within {s:.0f} s'))
     t.daemon = True
+    flag = _marker_path() + '.trial.' + os.environ.get('RANK', '0')    # "a deadline is armed on this rank": the launcher
+    with contextlib.suppress(OSError):                                 # of a rank that died otherwise waits for us
+        os.makedirs(os.path.dirname(flag), exist_ok=True)
+        open(flag, 'w').close()
     t.start()
     try:
         yield
     finally:
         t.cancel()
+        with contextlib.suppress(OSError):
+            os.remove(flag)
 
 
 def excluded():
@@ -120,10 +126,16 @@ def run(argv, max_attempts=8, log=None):
         if rc == 0:
             return 0
         # the rank that saw the deadline first wrote the marker; one that died of its peers' exit (a reset connection
-        # under gloo) gets here before them: wait for the marker as long as a peer's deadline can still be running
+        # under gloo) gets here before them: wait for the marker as long as some rank still has a deadline armed
+        # (its .trial flag); a rank that dies while nobody is inside a trial is an ordinary failure, handed on at once
         wait = (0.0 if rc == HUNG_EXIT else float(env['DGNN_FORM_DEADLINE_S']) + 30.0)
         t0 = time.time()
-        while not os.path.exists(marker) and time.time() - t0 < wait:
+
+        def trials():
+            d, base = os.path.dirname(marker), os.path.basename(marker) + '.trial.'
+            mine = base + env.get('RANK', '0')                       # our own child is gone: its flag means nothing now
+            return os.path.isdir(d) and any(n.startswith(base) and n != mine for n in os.listdir(d))
+        while not os.path.exists(marker) and time.time() - t0 < wait and trials():
             time.sleep(0.5)
         if not os.path.exists(marker):
             return rc

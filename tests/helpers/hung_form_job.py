@@ -28,7 +28,7 @@ def main():
     gcn.set_spmm_backend(_oracle_spmm, gather=_cpu_gather)
     env = dist_utils.DistEnv(rank, world, 'gloo', echo=False)
     form, how, who = (os.environ.get('DGNN_TEST_BREAK', '::-1').split(':') + ['-1'])[:3]
-    if form and int(who) == rank:
+    if form and how != 'crash' and int(who) == rank:
         name = {'allgather': '_run_allgather', 'agpipe': '_run_agpipe', 'needed_a2a': '_run_needed_a2a', 'bcast': '_run_bcast'}[form]
         real = getattr(gcn.StagePipeline, name)
         if how == 'hang':
@@ -57,6 +57,8 @@ def main():
     g = coo_graph.Parted_COO_Graph('tiny', rank, world, attr_dict=full.partition(world, save=False)[rank])
     feats = torch.from_numpy(w[f'r{rank}_features'])
     z = gcn.broadcast(g.adj_parts, feats, 'ForwardL1')
+    if how == 'crash' and int(who) == rank:                 # an ordinary failure, outside any trial
+        raise SystemExit(7)
     pipe = gcn.pipeline()
     (key, (picked, times)), = pipe.choice.items() if pipe.choice else [(None, (pipe.mode, {}))]
     print(json.dumps(dict(rank=rank, attempt=int(os.environ.get('DGNN_ATTEMPT', 0)), picked=picked, timed=sorted(times),

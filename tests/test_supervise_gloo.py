@@ -73,3 +73,17 @@ def test_the_reference_form_hanging_is_the_jobs_failure(tmp_path):
     for rc, o, e in outs:
         assert rc == 86, (rc, e[-2000:])
         assert 'DGNN_FORM_HUNG=bcast' in e and 'giving up' in e and 'restarting' not in e
+
+
+def test_an_ordinary_failure_is_handed_on_at_once(tmp_path):
+    """A rank that dies outside auto's trials (nobody has a deadline armed) is not mistaken for a hang: its launcher
+    returns its exit code without waiting a deadline out or restarting anything."""
+    import time
+    t0 = time.time()
+    port = _free_port()
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               DGNN_LOG_DIR=str(tmp_path), DGNN_HUNG_DIR=os.path.join(str(tmp_path), 'hung'), DGNN_FORM_DEADLINE_S='60',
+               DGNN_TEST_BREAK='bcast:crash:0', PYTHONPATH=os.path.join(ROOT, 'dist-gnn_amd') + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    p = subprocess.run([sys.executable, '-m', 'dist_utils.supervise', '--', sys.executable, JOB], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 7 and 'restarting' not in p.stderr and time.time() - t0 < 45

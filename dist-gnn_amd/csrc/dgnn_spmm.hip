@@ -970,22 +970,23 @@ constexpr int STRIP_LDS = STRIP_LDS_B + STRIP_NW * STRIP_RING * STRIP_LINE * 8;
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// Multiply the line at LDS address `ra` (lane l: dword l of the line) into the accumulators. The instruction stream comes from
-// tools/gen_strip_asm.py (groups of 4 entries, software-pipelined across two register sets): entry k of the line sits in
-// lanes 2k (slot << 11 | row * 4 [| header]) and 2k + 1 (value) of v28; v_readlane_b32 broadcasts it into an SGPR pair that
-// is the first operand of the packed FMAs as it stands (op_sel picks the value for both halves) and whose low byte is the
-// accumulator index; (pair.x & mask) | lane base is the LDS address of the column's slice. The line's first entry
-// carries the header: bits 20-23 the groups of 4 entries to take (1..8), bit 24 "last line of this strip". Returns bit 24;
-// k0..k3 = dwords 60..63 of the line (the first line of a block keeps column ids there, and at most 7 groups of entries).
-__device__ __forceinline__ uint32_t strip_line(f32x32& accA, f32x32& accB, uint32_t ra, uint32_t lb,
+// Multiply the line at LDS address `rb` (`ra` = rb + 4 * lane: lane l reads dword l) into the accumulators. The instruction
+// stream comes from tools/gen_strip_asm.py (groups of 4 entries, software-pipelined across two register sets). A line is 64
+// dwords: dword k = meta word of entry k (slot << 11 | row * 4 [| header]), dword 32 + k = its value. v_readlane_b32
+// broadcasts the meta word into an SGPR whose low byte is the accumulator index and whose slot field, (meta & mask) | lane
+// base, is the LDS address of the column's slice; the four values of a group reach every lane through one ds_read_b128 at a
+// wave-uniform address and are the first operand of the packed FMAs from there (op_sel picks the half). The line's first
+// entry carries the header: bits 20-23 the groups of 4 entries to take (1..8), bit 24 "last line of this strip". Returns bit
+// 24; k0..k3 = dwords 28..31 of the line (the first line of a block keeps column ids there, and at most 7 groups of entries).
+__device__ __forceinline__ uint32_t strip_line(f32x32& accA, f32x32& accB, uint32_t ra, uint32_t rb, uint32_t lb,
                                                int& k0, int& k1, int& k2, int& k3) {
   const uint32_t mask = 0x0003fe00u;
   uint32_t last;
   asm volatile(
 #include "strip_line_asm.inc"
       : "+{v[64:95]}"(accA), "+{v[96:127]}"(accB), [last] "=&s"(last), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
-      : [ra] "v"(ra), [mask] "v"(mask), [lb] "v"(lb)
-      : "v24", "v25", "v26", "v27", "v28", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",
+      : [ra] "v"(ra), [rb] "v"(rb), [mask] "v"(mask), [lb] "v"(lb)
+      : "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v24", "v25", "v26", "v27", "v28", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",
         "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
         "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "scc", "memory");
   return last;
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
   }
   const uint32_t* lp = ent + ebase[(int64_t)piece * STRIP_NW + wave] * (STRIP_LINE * 2) + lane;   // next line to request, this lane's dword
   unsigned char* const ring = lds + STRIP_LDS_B + wave * (STRIP_RING * STRIP_LINE * 8);
-  const uint32_t ring_ra = (uint32_t)(STRIP_LDS_B + wave * (STRIP_RING * STRIP_LINE * 8) + lane * 4);
+  const uint32_t ring_rb = (uint32_t)(STRIP_LDS_B + wave * (STRIP_RING * STRIP_LINE * 8));
   int c0, c1, c2, c3;                                          // columns of the wave's four slots of the next strip to fill
   STRIP_COLS(0, c0, c1, c2, c3)
   STRIP_FILL(0, c0, c1, c2, c3)
@@ -1084,7 +1085,8 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
     ws = ws == STRIP_RING - 1 ? 0 : ws + 1;
     const uint32_t lb = (uint32_t)lane * 8u + (uint32_t)(s & 1) * 1024u;
     int n0, n1, n2, n3;
-    const uint32_t last = strip_line(accA, accB, ring_ra + rs * (STRIP_LINE * 8), lb, n0, n1, n2, n3);
+    const uint32_t rb = ring_rb + rs * (STRIP_LINE * 8);
+    const uint32_t last = strip_line(accA, accB, rb + (uint32_t)lane * 4u, rb, lb, n0, n1, n2, n3);
     if (first) { c0 = n0; c1 = n1; c2 = n2; c3 = n3; }          // a block's first line names the columns of strip s + 2
     rs = rs == STRIP_RING - 1 ? 0 : rs + 1;
     first = last;
@@ -1571,7 +1573,7 @@ size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" {
 
-int dgnn_version(void) { return 260; }   // 260: dgnn_strip_plan, dgnn_spmm_strip_f32, dgnn_prof_end_by_kernel, dgnn_set_variant only in -DDGNN_EXPERIMENTS builds; 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
+int dgnn_version(void) { return 270; }   // 270: dgnn_strip_plan.ent lines hold the 32 meta words first, then the 32 values; 260: dgnn_strip_plan, dgnn_spmm_strip_f32, dgnn_prof_end_by_kernel, dgnn_set_variant only in -DDGNN_EXPERIMENTS builds; 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 

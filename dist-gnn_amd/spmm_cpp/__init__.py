@@ -93,7 +93,7 @@ for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_ABI = 260                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+_ABI = 270                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
 if _lib.dgnn_version() != _ABI:
     raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
                        'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')
@@ -1232,15 +1232,19 @@ class StripPlan:
         nl = 1 + torch.clamp(bcnt - FIRST + LINE - 1, min=0) // LINE
         lstart = torch.cumsum(nl, 0) - nl
         nline = int(nl.sum().item()) if nblocks else 0
-        ent = torch.empty((nline + 4) * LINE, 2, dtype=torch.int32, device=dev)  # (+ slack: the kernel requests two lines ahead)
-        ent[:, 0] = WMAX << 11                                    # pad entries: the all-zero slice ...
-        ent[:, 1] = -2147483648                                   # ... times -0.0: fma(-0.0, +0.0, acc) == acc for every acc
+        # a line = 64 dwords: the 32 entries' meta words, then their 32 values
+        ent = torch.empty((nline + 8), 2, LINE, dtype=torch.int32, device=dev)  # (+ slack: the kernel requests up to six lines ahead)
+        ent[:, 0, :] = WMAX << 11                                 # pad entries: the all-zero slice ...
+        ent[:, 1, :] = -2147483648                                # ... times -0.0: fma(-0.0, +0.0, acc) == acc for every acc
+        flat = ent.view(-1)
         if moved:
             later = torch.clamp(rank_in - FIRST, min=0)
-            pos = torch.where(rank_in < FIRST, lstart[sb] * LINE + rank_in, (lstart[sb] + 1 + later // LINE) * LINE + later % LINE)
-            ent[pos, 0] = ((e_slot[perm] << 11) | (e_rsub[perm] * 4)).int()
-            ent[pos, 1] = e_val[perm].view(torch.int32)
-            del perm, bfirst, sb, pos, bidx, e_slot, e_rsub, e_val, rank_in, later
+            eline = torch.where(rank_in < FIRST, lstart[sb], lstart[sb] + 1 + later // LINE)
+            eidx = torch.where(rank_in < FIRST, rank_in, later % LINE)
+            pos = eline * (2 * LINE) + eidx
+            flat[pos] = ((e_slot[perm] << 11) | (e_rsub[perm] * 4)).int()
+            flat[pos + LINE] = e_val[perm].view(torch.int32)
+            del perm, bfirst, sb, pos, bidx, e_slot, e_rsub, e_val, rank_in, later, eline, eidx
         if nline:
             lblk = torch.repeat_interleave(torch.arange(nblocks, **i64), nl)
             l_in = torch.arange(nline, **i64) - lstart[lblk]
@@ -1248,17 +1252,17 @@ class StripPlan:
                               torch.clamp(bcnt[lblk] - FIRST - LINE * (l_in - 1), min=0, max=LINE))
             ng = torch.clamp((rem + 3) // 4, min=1)
             hdr = (ng << 20) | ((l_in == nl[lblk] - 1).long() << 24)
-            ent[torch.arange(nline, **i64) * LINE, 0] |= hdr.int()
+            flat[torch.arange(nline, **i64) * (2 * LINE)] |= hdr.int()
             del lblk, l_in, rem, ng, hdr
-            # the first line of the block of (piece, wave w, strip sp) names the columns of slots 4 w .. 4 w + 3 of strip sp + 2
+            # the first line of the block of (piece, wave w, strip sp) names the columns of slots 4 w .. 4 w + 3 of strip
+            # sp + 2, in the meta words of its last four entry slots (a first line holds at most 28 entries)
             bp = torch.repeat_interleave(torch.arange(npiece, **i64), pnsp * NW)      # blocks are numbered piece after piece
             within = torch.arange(nblocks, **i64) - (psb * NW)[bp]
             bw, bsp = within // pnsp[bp], within % pnsp[bp]
             kk = pk0[bp][:, None] + ((bsp + 2) * w_t[ptile][bp] + bw * 4)[:, None] + torch.arange(4, **i64)[None, :]
             kk = torch.minimum(torch.maximum(kk, pk0[bp][:, None]), (pk1[bp] - 1)[:, None])
             ids = self.ucol[kk.view(-1)].view(-1, 4)
-            flat = ent.view(-1)
-            at = (lstart * (2 * LINE) + 2 * LINE - 4)[:, None] + torch.arange(4, **i64)[None, :]
+            at = (lstart * (2 * LINE) + LINE - 4)[:, None] + torch.arange(4, **i64)[None, :]
             flat[at.view(-1)] = ids.view(-1)
             del bp, within, bw, bsp, kk, ids, at
         self.ent = ent

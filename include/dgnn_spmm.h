@@ -291,12 +291,12 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
  *           into C, else the piece sums go to partial rows out + i and are merged per row (cut list {row, first partial
  *           row, pieces, 255}, as in dgnn_plan)
  *   ebase   device, int64[16 * npiece]: first line of (piece, wave)'s entry stream
- *   ent     device, 256-byte aligned, uint32[64 * nline (+ 256 of slack)]: lines of 32 entries {slot << 11 | member
- *           row / 16 * 4, value bits}; the entries of (piece, wave, strip) are a block of whole lines, blocks in strip
- *           order; a line's first entry also carries, in bits 20-23, the groups of 4 entries to take from the line (1..8)
- *           and, in bit 24, "last line of its block"; the FIRST line of the block of strip s holds at most 28 entries and,
- *           in its last four dwords, the columns of the wave's slots 4 w .. 4 w + 3 of strip s + 2 (clamped into
- *           [k0, k1 - 1]); pad entries {64 << 11, 0x80000000 (-0.0)}
+ *   ent     device, 256-byte aligned, uint32[64 * nline (+ 256 of slack)]: lines of 32 entries; dword k of a line is entry
+ *           k's meta word (slot << 11 | member row / 16 * 4), dword 32 + k its value bits; the entries of (piece, wave,
+ *           strip) are a block of whole lines, blocks in strip order; a line's first meta word also carries, in bits 20-23,
+ *           the groups of 4 entries to take from the line (1..8) and, in bit 24, "last line of its block"; the FIRST line
+ *           of the block of strip s holds at most 28 entries and, in meta words 28..31, the columns of the wave's slots
+ *           4 w .. 4 w + 3 of strip s + 2 (clamped into [k0, k1 - 1]); pad entries {64 << 11, 0x80000000 (-0.0)}
  *   npartial  rows the partial buffer must hold
  * Every row sums its own nonzeros in ascending column order starting from what C holds, one fused multiply-add each:
  * rows of uncut tiles carry the bits of dgnn_spmm_csr_f32; rows of cut tiles the fixed-order piece sums. Pad entries

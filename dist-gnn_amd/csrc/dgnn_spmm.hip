@@ -992,6 +992,38 @@ __device__ __forceinline__ uint32_t strip_line(f32x32& accA, f32x32& accB, uint3
   return last;
 }
 
+#ifdef DGNN_EXPERIMENTS
+// Timing experiments only (never in the product library): the same line walk with the slices' LDS reads or the packed FMAs
+// left out (tools/gen_strip_asm.py noread | nofma). Same addresses, same waits on everything that carries an address.
+__device__ __forceinline__ uint32_t strip_line_noread(f32x32& accA, f32x32& accB, uint32_t ra, uint32_t rb, uint32_t lb,
+                                                      int& k0, int& k1, int& k2, int& k3) {
+  const uint32_t mask = 0x0003fe00u;
+  uint32_t last;
+  asm volatile(
+#include "strip_line_asm_noread.inc"
+      : "+{v[64:95]}"(accA), "+{v[96:127]}"(accB), [last] "=&s"(last), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
+      : [ra] "v"(ra), [rb] "v"(rb), [mask] "v"(mask), [lb] "v"(lb)
+      : "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v24", "v25", "v26", "v27", "v28", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",
+        "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+        "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "scc", "memory");
+  return last;
+}
+__device__ __forceinline__ uint32_t strip_line_nofma(f32x32& accA, f32x32& accB, uint32_t ra, uint32_t rb, uint32_t lb,
+                                                     int& k0, int& k1, int& k2, int& k3) {
+  const uint32_t mask = 0x0003fe00u;
+  uint32_t last;
+  asm volatile(
+#include "strip_line_asm_nofma.inc"
+      : "+{v[64:95]}"(accA), "+{v[96:127]}"(accB), [last] "=&s"(last), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
+      : [ra] "v"(ra), [rb] "v"(rb), [mask] "v"(mask), [lb] "v"(lb)
+      : "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v24", "v25", "v26", "v27", "v28", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",
+        "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+        "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "scc", "memory");
+  return last;
+}
+#endif
+
+template <int LV>                                 // 0: the product's line walk; 1 / 2: timing experiments (-DDGNN_EXPERIMENTS only)
 __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
     const int32_t* __restrict__ desc, int32_t npiece, const int32_t* __restrict__ rows, const int32_t* __restrict__ ucol,
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ ebase,
@@ -1086,7 +1118,13 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
     const uint32_t lb = (uint32_t)lane * 8u + (uint32_t)(s & 1) * 1024u;
     int n0, n1, n2, n3;
     const uint32_t rb = ring_rb + rs * (STRIP_LINE * 8);
-    const uint32_t last = strip_line(accA, accB, rb + (uint32_t)lane * 4u, rb, lb, n0, n1, n2, n3);
+    uint32_t last;
+#ifdef DGNN_EXPERIMENTS
+    if constexpr (LV == 1) last = strip_line_noread(accA, accB, rb + (uint32_t)lane * 4u, rb, lb, n0, n1, n2, n3);
+    else if constexpr (LV == 2) last = strip_line_nofma(accA, accB, rb + (uint32_t)lane * 4u, rb, lb, n0, n1, n2, n3);
+    else
+#endif
+    last = strip_line(accA, accB, rb + (uint32_t)lane * 4u, rb, lb, n0, n1, n2, n3);
     if (first) { c0 = n0; c1 = n1; c2 = n2; c3 = n3; }          // a block's first line names the columns of strip s + 2
     rs = rs == STRIP_RING - 1 ? 0 : rs + 1;
     first = last;
@@ -1957,9 +1995,18 @@ int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
   const int vwc = (ldc % 4 == 0 && aligned(C, 16)) ? 4 : (vw2 ? 2 : 1);
   {
     ProfScope prof(s, K_STRIP);
-    hipLaunchKernelGGL(spmm_strip_kernel, dim3((unsigned)nitems), dim3(STRIP_NW * 64), 0, s, plan->desc, plan->npiece, plan->rows,
-                       plan->ucol, plan->ent, plan->ebase, B, ldb, C, ldc, partial, ldp, F, vw2,
-                       g_variant == 502 ? 2 : (g_variant == 504 ? 4 : (g_variant == 506 ? 6 : 0)));   // timing experiments: 2 no fills, 4 no barrier (wrong sums, in-bounds)
+    // timing experiments (experiments build; wrong sums, in-bounds): variant 500 + bits: 2 no fills, 4 no barrier, 8 no slice reads, 16 no FMAs
+    const int dbg = (g_variant >= 500 && g_variant < 532) ? ((g_variant - 500) & 0x1e) : 0;
+#define DGNN_STRIP_LAUNCH(LV)                                                                                            \
+    hipLaunchKernelGGL(spmm_strip_kernel<LV>, dim3((unsigned)nitems), dim3(STRIP_NW * 64), 0, s, plan->desc, plan->npiece, plan->rows, \
+                       plan->ucol, plan->ent, plan->ebase, B, ldb, C, ldc, partial, ldp, F, vw2, dbg & 6)
+#ifdef DGNN_EXPERIMENTS
+    if (dbg & 8) DGNN_STRIP_LAUNCH(1);
+    else if (dbg & 16) DGNN_STRIP_LAUNCH(2);
+    else
+#endif
+    DGNN_STRIP_LAUNCH(0);
+#undef DGNN_STRIP_LAUNCH
     DGNN_HIP(hipGetLastError());
   }
   if (plan->ncut > 0) {

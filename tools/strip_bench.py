@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--max-ratio', default='0.5')
     ap.add_argument('--piece', default='0', help='strips per piece (0 = the plan builder\'s rule)')
     ap.add_argument('--block', default='26', help='entries a wave should find in one strip (sets the strip width per tile)')
-    ap.add_argument('--variants', default='', help='library debug variants to time the strip kernel with (502: no fills)')
+    ap.add_argument('--variants', default='', help='library debug variants to time the strip kernel with (500 + bits: 2 no fills, 4 no barrier, 8 no slice reads, 16 no FMAs)')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--no-base', action='store_true')
     ap.add_argument('--dense', default='', help='min_count values: dense tiles first (DensePlan), strips on their remainder')
@@ -93,7 +93,7 @@ def main():
                 for v in [int(x) for x in args.variants.split(',') if x]:
                     spmm_cpp.set_variant(v)
                     mv, _ = time_call(lambda: spmm_cpp.spmm_strip(S, Bp, C, 1.0), args.iters, 2)
-                    print(f'    variant {v} (1: no FMAs, 2: no fills): strips {mv:.3f} ms', flush=True)
+                    print(f'    variant {v} (500 + bits: 2 no fills, 4 no barrier, 8 no slice reads, 16 no FMAs): strips {mv:.3f} ms', flush=True)
                 spmm_cpp.set_variant(0)
                 mr_, _ = time_call(lambda: spmm_cpp.spmm_plan(S.rest, Bp, C, 1.0, 1.0, rp), args.iters, 2)
                 print(f'F={F:4d} strips + {type(rp).__name__:10s}: {med:8.3f} ms (best {best:.3f}) = strips {ms:.3f} + rest {mr_:.3f}; '

@@ -1069,20 +1069,30 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
   // The wave's entry stream is a sequence of 256-byte lines (32 entries; a block = the entries of one strip = whole lines),
   // so the requests simply walk it; what a line holds is in its header. Column ids come through the scalar cache
   // (wave-uniform, requested a strip ahead).
-  const char* const Bb = reinterpret_cast<const char*>(B) + (int64_t)chunk * (STRIP_CH * 4) + lane * 16;
-  const bool dma = chunk * STRIP_CH + lane * 4 < (int)ldb && !(dbg & 2);     // lanes past the padded width move nothing (dbg: timing experiments)
+  // every lane moves 16 bytes of the slice; lanes past the padded width of the last chunk re-read the row's last 16 bytes
+  // instead (in bounds; what lands in their part of the LDS image feeds accumulator lanes that are never stored), so the
+  // requests need no per-lane predicate: the conditions below are wave-uniform and cost scalar branches only
+  const int64_t lane_off = min((int64_t)chunk * (STRIP_CH * 4) + lane * 16, (int64_t)ldb * 4 - 16);
+  const char* const Bb = reinterpret_cast<const char*>(B) + lane_off;
+  const bool dma = !(dbg & 2);                                 // (dbg: timing experiments)
   const uint64_t ldb_bytes = (uint64_t)ldb * 4u;
   const int wslot = wave * 4;                                  // wave w moves slots 4 w .. 4 w + 3 of a strip
   const int kw = k0 + wslot;
+  const bool wide = wslot + 3 < Wt;                            // this wave has four slots in every strip of the piece
   // (one 1-KiB instruction per slice: lane l copies floats 4l .. 4l+3, so the LDS image is the slice in its own order)
+#define STRIP_DMA(C, OFF) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C) * ldb_bytes), (lds_void_ptr)(dst + (OFF)), 16, 0, 0)
 #define STRIP_FILL(S, C0, C1, C2, C3)                                                                                   \
-  {                                                                                                                     \
+  if (dma) {                                                                                                            \
     const int kk = kw + (S) * Wt;                                                                                       \
     unsigned char* const dst = lds + (2 * wslot + ((S) & 1)) * 1024;                                                    \
-    if (wslot + 0 < Wt && kk + 0 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C0) * ldb_bytes), (lds_void_ptr)(dst), 16, 0, 0);        \
-    if (wslot + 1 < Wt && kk + 1 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C1) * ldb_bytes), (lds_void_ptr)(dst + 2048), 16, 0, 0); \
-    if (wslot + 2 < Wt && kk + 2 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C2) * ldb_bytes), (lds_void_ptr)(dst + 4096), 16, 0, 0); \
-    if (wslot + 3 < Wt && kk + 3 < k1 && dma) __builtin_amdgcn_global_load_lds((const void*)(Bb + (uint64_t)(uint32_t)(C3) * ldb_bytes), (lds_void_ptr)(dst + 6144), 16, 0, 0); \
+    if (wide && kk + 3 < k1) {                                 /* the common case: no further tests */                  \
+      STRIP_DMA(C0, 0); STRIP_DMA(C1, 2048); STRIP_DMA(C2, 4096); STRIP_DMA(C3, 6144);                                  \
+    } else {                                                                                                            \
+      if (wslot + 0 < Wt && kk + 0 < k1) STRIP_DMA(C0, 0);                                                              \
+      if (wslot + 1 < Wt && kk + 1 < k1) STRIP_DMA(C1, 2048);                                                           \
+      if (wslot + 2 < Wt && kk + 2 < k1) STRIP_DMA(C2, 4096);                                                           \
+      if (wslot + 3 < Wt && kk + 3 < k1) STRIP_DMA(C3, 6144);                                                           \
+    }                                                                                                                   \
   }
 #define STRIP_COLS(S, C0, C1, C2, C3)                                                                                   \
   {                                                                                                                     \
@@ -1131,6 +1141,7 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
     s += (int)last;
   }
 #undef STRIP_FILL
+#undef STRIP_DMA
 #undef STRIP_COLS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the last requests land before the LDS goes back
 

@@ -270,7 +270,7 @@ def test_older_extension_name_and_signatures():
     assert sparse_coo_tensor_gpu(idx[:, :1], torch.tensor(2.0, device=dev), (n, m))._values().shape == (1,)
 
 
-@pytest.mark.parametrize('kind', ['runs', 'bundles', 'tiles'])
+@pytest.mark.parametrize('kind', ['runs', 'bundles', 'tiles', 'strips'])
 def test_plan_spmm_can_be_captured_in_a_hip_graph(kind):
     """The fast-path entry points only launch kernels on the given stream (no allocation, no synchronisation),
     so a caller may capture them in a HIP graph and replay it on new operand contents: run plans, bundle plans, and
@@ -289,11 +289,15 @@ def test_plan_spmm_can_be_captured_in_a_hip_graph(kind):
         plan = spmm_cpp.SegPlan(blk, 3, 64)             # three stages, cut rows: stage kernels + merge kernels
     elif kind == 'bundles':
         plan = spmm_cpp.BundlePlan(blk, 3, 4, 64)
+    elif kind == 'strips':                               # row strips (cut tiles: partial rows + merge) after the plan of the rest
+        S = spmm_cpp.StripPlan(blk, 0.6, 4, min_tile_nnz=64)
+        assert S.npiece > 0 and S.ncut > 0                 # (every tile is selected here: the plan of the rest only overwrites C)
+        plan = spmm_cpp.StripHybridPlan(S, spmm_cpp.SegPlan(S.rest, 2, 64))
     else:
         D = spmm_cpp.DensePlan(blk, 3, 8, 64)
         assert D.nk > 0 and D.ncut > 0
         plan = spmm_cpp.HybridPlan(D, spmm_cpp.SegPlan(D.rest, 2, 64))
-    assert (plan.rest_plan if kind == 'tiles' else plan).ncut > 0
+    assert (plan.strip if kind == 'strips' else plan.rest_plan if kind == 'tiles' else plan).ncut > 0
     B = spmm_cpp.pad_rows(torch.rand(m, F, device=dev))
     C = torch.zeros(n, F, device=dev)
     spmm_cpp.spmm_plan(blk, B, C, 1.0, 0.0, plan)       # warm-up: sizes the partial buffer outside the capture

@@ -1099,7 +1099,8 @@ def spmm_dense(D, B, C, alpha=1.0):
 
 
 # --------------------------------------------------------------------------- row strips (B slices staged in LDS)
-STRIP_R, STRIP_NW, STRIP_W, STRIP_LINE = 256, 16, 64, 32     # rows per tile, waves per workgroup, widest strip, entries per line (the kernel's geometry)
+STRIP_R, STRIP_NW, STRIP_W, STRIP_LINE = 256, 16, 64, 32
+_STRIP_BITMAP_LIMIT = 2 ** 31          # (tile, column) cells up to which a tile's union comes from a bitmap (tests lower it: the sort path)     # rows per tile, waves per workgroup, widest strip, entries per line (the kernel's geometry)
 
 
 class StripPlan:
@@ -1138,49 +1139,83 @@ class StripPlan:
             raise ValueError('piece_strips must not be negative')
         self.max_ratio = float(max_ratio)
         i64 = dict(dtype=torch.long, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
         rp = A.rowptr.long()
         deg = rp[1:] - rp[:-1]
         ntile = max(1, -(-n // R))
-        order = torch.argsort(deg, descending=True, stable=True)
-        rank = torch.empty_like(order)
-        rank[order] = torch.arange(n, **i64)
-        row_idx = torch.repeat_interleave(torch.arange(n, **i64), deg)
-        rnk = rank[row_idx]
-        tile = rnk // R
-        col = A.col.long()
-        ukey, inv = torch.unique(tile * m + col, return_inverse=True)           # sorted: by tile, then column
-        utile = ukey // m
-        usz = torch.bincount(utile, minlength=ntile)
-        ssz = torch.bincount(tile, minlength=ntile)
+        order = torch.argsort(deg, descending=True, stable=True)            # order[j] = the row of rank j
+        tile_of_row = torch.empty(n, **i64)
+        tile_of_row[order] = torch.arange(n, **i64) // R
+        # The entries in RANK order (row of rank 0 first), columns ascending inside a row -- a gather, not a sort. Everything
+        # per entry below is int32 and lives in this order: inside a (wave, strip) block it is already the order the kernel
+        # wants (row, then column), so the one sort left is a stable sort by block number.
+        deg_r = deg[order]
+        j_e = torch.repeat_interleave(torch.arange(n, **i32), deg_r)        # rank of the entry's row
+        start_r = torch.cumsum(deg_r, 0) - deg_r
+        src = (rp[order] - start_r).int()[j_e] + torch.arange(nnz, **i32)   # where the entry sits in the CSR arrays
+        del start_r
+        col_r = A.col[src]
+        tile_e = j_e // R
+        ssz = torch.bincount(tile_e, minlength=ntile)
+        bitmap = ntile * m < _STRIP_BITMAP_LIMIT
+        if bitmap:
+            # union of a tile's columns through a (tile, column) bitmap: no sort over the nonzeros
+            key = tile_e * m + col_r
+            present = torch.zeros(ntile * m, dtype=torch.bool, device=dev)
+            present[key] = True
+            pm = present.view(ntile, m)
+            usz = pm.sum(1)
+            slot = torch.cumsum(pm, 1, dtype=torch.int32).view(-1)          # 1 + position inside the tile's sorted union
+            e_uslot = slot[key] - 1
+            del slot, key
+            ukey = None
+        else:
+            key = tile_e.long() * m + col_r
+            ukey, inv = torch.unique(key, return_inverse=True)              # sorted: by tile, then column
+            del key
+            utile = ukey // m
+            usz = torch.bincount(utile, minlength=ntile)
+            e_uslot = (inv - (torch.cumsum(usz, 0) - usz)[tile_e]).int()
+            del inv
+        del col_r
         ok_t = (ssz >= max(int(min_tile_nnz), 1)) & (usz.double() <= self.max_ratio * ssz.double())
-        sel_u, sel_e = ok_t[utile], ok_t[tile]
-        # what stays: a CsrBlock of its own (whole rows: a tile is taken or left as a whole)
-        keep = ~sel_e
+        # what stays: a CsrBlock of its own (whole rows: a tile is taken or left as a whole), in the block's own order
+        keep_row = ~ok_t[tile_of_row]
+        keep = torch.repeat_interleave(keep_row, deg)
         rest_rp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-        rest_rp[1:] = torch.cumsum(torch.bincount(row_idx[keep], minlength=n), 0).int()
+        rest_rp[1:] = torch.cumsum(deg * keep_row, 0).int()
         self.rest = CsrBlock(n, m, rest_rp, A.col[keep].contiguous(), A.val[keep].contiguous())
-        del keep, row_idx
+        self.rest._distinct = True
+        del keep, keep_row
+        sel_e = ok_t[tile_e]
         moved = int(sel_e.sum().item())
         self.share = moved / max(nnz, 1)
         # the selected tiles' union lists, compacted
         usz_s = torch.where(ok_t, usz, torch.zeros_like(usz))
         first = torch.cumsum(usz_s, 0) - usz_s
-        cpos = torch.cumsum(sel_u.long(), 0) - 1
-        self.ucol = (ukey % m)[sel_u].int().contiguous() if moved else torch.zeros(1, dtype=torch.int32, device=dev)
         nu = int(usz_s.sum().item())
+        if not moved:
+            self.ucol = torch.zeros(1, dtype=torch.int32, device=dev)
+        elif ukey is None:
+            self.ucol = torch.nonzero(pm & ok_t[:, None])[:, 1].int().contiguous()      # row-major: by tile, then column
+        else:
+            self.ucol = (ukey % m)[ok_t[utile]].int().contiguous()
+            del ukey, utile
+        if bitmap:
+            del present, pm
         self.nu = nu
         self.union_ratio = nu / max(moved, 1)
-        e_tile = tile[sel_e]
-        e_uslot = cpos[inv[sel_e]] - first[e_tile]
-        e_i = rnk[sel_e] % R
-        e_val = A.val[sel_e]
-        del ukey, inv, utile, sel_u, cpos, tile, rnk, col, sel_e
+        e_tile = tile_e[sel_e]
+        e_uslot = e_uslot[sel_e]
+        e_i = j_e[sel_e] % R
+        e_val = A.val[src[sel_e]]
+        del tile_e, j_e, src, sel_e
         # strip width of every tile: the widest of 64 / 32 / 16 / 8 that keeps a wave's share of a strip near one line
         per_col = ssz.double() / usz.clamp(min=1).double() / NW                 # entries per wave and union column
         w_t = torch.full((ntile,), WMAX, **i64)
         for w in (WMAX // 2, WMAX // 4, WMAX // 8):
             w_t = torch.where(per_col * (2 * w) > float(block_target), torch.full_like(w_t, w), w_t)
-        w_e = w_t[e_tile]
+        w_e = w_t.int()[e_tile]
         e_strip, e_slot = e_uslot // w_e, e_uslot % w_e
         e_wave, e_rsub = e_i % NW, e_i // NW
         del e_uslot, e_i, w_e
@@ -1218,14 +1253,16 @@ class StripPlan:
         # a whole number of lines (at least one: an empty block still tells the wave to move on to the next strip)
         nblocks = nstrips * NW
         if moved:
-            e_p = pbase_t[e_tile] + e_strip // spp_t[e_tile].clamp(min=1)
-            bidx = psb[e_p] * NW + e_wave * pnsp[e_p] + (e_strip - ps0[e_p])
+            e_p = pbase_t.int()[e_tile] + e_strip // spp_t.clamp(min=1).int()[e_tile]
+            bidx = psb.int()[e_p] * NW + e_wave * pnsp.int()[e_p] + (e_strip - ps0.int()[e_p])
             del e_p, e_strip, e_wave, e_tile
-            perm = torch.argsort((bidx * RW + e_rsub) * WMAX + e_slot)
+            # rank order = (row, column) order inside every block already: a stable sort by block number finishes it
+            sb, perm = torch.sort(bidx, stable=True)
             bcnt = torch.bincount(bidx, minlength=nblocks)
             bfirst = torch.cumsum(bcnt, 0) - bcnt
-            sb = bidx[perm]
-            rank_in = torch.arange(moved, **i64) - bfirst[sb]
+            del bidx
+            rank_in = torch.arange(moved, **i32) - bfirst.int()[sb]           # position inside the block
+            del bfirst
         else:
             bcnt = torch.zeros(nblocks, **i64)
         FIRST = LINE - 4                                           # a block's first line: 28 entries + 4 column ids
@@ -1238,13 +1275,17 @@ class StripPlan:
         ent[:, 1, :] = -2147483648                                # ... times -0.0: fma(-0.0, +0.0, acc) == acc for every acc
         flat = ent.view(-1)
         if moved:
+            if (nline + 8) * 2 * LINE >= 2 ** 31:
+                raise RuntimeError('StripPlan: entry stream exceeds int32 indexing')
             later = torch.clamp(rank_in - FIRST, min=0)
-            eline = torch.where(rank_in < FIRST, lstart[sb], lstart[sb] + 1 + later // LINE)
-            eidx = torch.where(rank_in < FIRST, rank_in, later % LINE)
-            pos = eline * (2 * LINE) + eidx
-            flat[pos] = ((e_slot[perm] << 11) | (e_rsub[perm] * 4)).int()
+            l32 = lstart.int()[sb]
+            del sb
+            pos = torch.where(rank_in < FIRST, l32 * (2 * LINE) + rank_in, (l32 + 1 + later // LINE) * (2 * LINE) + later % LINE)
+            del l32, later, rank_in
+            flat[pos] = (e_slot[perm] << 11) | (e_rsub[perm] * 4)
+            del e_slot, e_rsub
             flat[pos + LINE] = e_val[perm].view(torch.int32)
-            del perm, bfirst, sb, pos, bidx, e_slot, e_rsub, e_val, rank_in, later, eline, eidx
+            del perm, pos, e_val
         if nline:
             lblk = torch.repeat_interleave(torch.arange(nblocks, **i64), nl)
             l_in = torch.arange(nline, **i64) - lstart[lblk]

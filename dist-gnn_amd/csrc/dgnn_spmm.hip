@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
     const int32_t* __restrict__ desc, int32_t npiece, const int32_t* __restrict__ rows, const int32_t* __restrict__ ucol,
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ ebase,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-    float* __restrict__ P, int64_t ldp, int32_t F, int vw2, int dbg) {
+    float* __restrict__ P, int64_t ldp, int32_t F, int vw2, int dbg, int fresh) {
   __shared__ __align__(16) unsigned char lds[STRIP_LDS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(STRIP_NW * 64) void spmm_strip_kernel(
 #pragma unroll
   for (int j = 0; j < STRIP_RW; ++j) {
     f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
-    if (direct) {
+    if (direct && !fresh) {                                    // fresh: the tile's rows have no value yet -- C is written, not read
       const int row = rw[j * STRIP_NW + wave];
       if (row >= 0) {
         if (act0) lo = c2_load(C + (int64_t)row * ldc + f0, f0, F, v2);
@@ -1622,7 +1622,7 @@ size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" {
 
-int dgnn_version(void) { return 270; }   // 270: dgnn_strip_plan.ent lines hold the 32 meta words first, then the 32 values; 260: dgnn_strip_plan, dgnn_spmm_strip_f32, dgnn_prof_end_by_kernel, dgnn_set_variant only in -DDGNN_EXPERIMENTS builds; 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
+int dgnn_version(void) { return 280; }   // 280: dgnn_spmm_strip_overwrite_f32; 270: dgnn_strip_plan.ent lines hold the 32 meta words first, then the 32 values; 260: dgnn_strip_plan, dgnn_spmm_strip_f32, dgnn_prof_end_by_kernel, dgnn_set_variant only in -DDGNN_EXPERIMENTS builds; 250: dgnn_dense_plan, dgnn_spmm_dense_f32; 240: dgnn_bundle_plan, dgnn_spmm_bundle_f32; 230: dgnn_plan.hot_rows / hot_cols / seg_hot; 220: dgnn_spmm_coo_noalloc_f32 (210: dgnn_plan.covers_rows, dgnn_spmm_plan_overwrite_f32)
 
 const char* dgnn_last_error(void) { return g_err; }
 
@@ -1979,9 +1979,9 @@ int dgnn_spmm_dense_f32(const dgnn_dense_plan* plan, int32_t n, int32_t m,
   return DGNN_OK;
 }
 
-int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
-                        const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
-                        int32_t F, float alpha, void* stream) {
+static int spmm_strip_impl(const dgnn_strip_plan* plan, int32_t n, int32_t m,
+                           const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                           int32_t F, float alpha, int fresh, void* stream) {
   if (!plan) return fail(DGNN_E_BADARG, "spmm_strip: null plan%s", "");
   if (plan->rows_per_tile != STRIP_R || plan->strip_cols != STRIP_W || plan->waves != STRIP_NW || plan->line_entries != STRIP_LINE)
     return fail(DGNN_E_BADARG, "spmm_strip: plan geometry must be 256 rows per tile, at most 64 columns per strip, 16 waves, 32 entries per line%s", "");
@@ -2010,7 +2010,7 @@ int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
     const int dbg = (g_variant >= 500 && g_variant < 532) ? ((g_variant - 500) & 0x1e) : 0;
 #define DGNN_STRIP_LAUNCH(LV)                                                                                            \
     hipLaunchKernelGGL(spmm_strip_kernel<LV>, dim3((unsigned)nitems), dim3(STRIP_NW * 64), 0, s, plan->desc, plan->npiece, plan->rows, \
-                       plan->ucol, plan->ent, plan->ebase, B, ldb, C, ldc, partial, ldp, F, vw2, dbg & 6)
+                       plan->ucol, plan->ent, plan->ebase, B, ldb, C, ldc, partial, ldp, F, vw2, dbg & 6, fresh)
 #ifdef DGNN_EXPERIMENTS
     if (dbg & 8) DGNN_STRIP_LAUNCH(1);
     else if (dbg & 16) DGNN_STRIP_LAUNCH(2);
@@ -2022,10 +2022,22 @@ int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
   }
   if (plan->ncut > 0) {
     ProfScope prof(s, K_MERGE);
-    launch_merge(vwc, reinterpret_cast<const int4*>(plan->cut), plan->ncut, partial, ldp, C, ldc, F, 0, s);
+    launch_merge(vwc, reinterpret_cast<const int4*>(plan->cut), plan->ncut, partial, ldp, C, ldc, F, fresh, s);
     DGNN_HIP(hipGetLastError());
   }
   return DGNN_OK;
+}
+
+int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                        int32_t F, float alpha, void* stream) {
+  return spmm_strip_impl(plan, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, 0, stream);
+}
+
+int dgnn_spmm_strip_overwrite_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
+                                  const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                                  int32_t F, float alpha, void* stream) {
+  return spmm_strip_impl(plan, n, m, B, ldb, C, ldc, partial, ldp, F, alpha, 1, stream);
 }
 
 static int spmm_plan_impl(const dgnn_plan* plan, const int32_t* col, const float* val,

@@ -87,13 +87,14 @@ _SIGNATURES = {                          # argument types, in the order of inclu
     'dgnn_spmm_bundle_f32': [ctypes.POINTER(_CBundlePlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _f32, _p],
     'dgnn_spmm_dense_f32': [ctypes.POINTER(_CDensePlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
     'dgnn_spmm_strip_f32': [ctypes.POINTER(_CStripPlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
+    'dgnn_spmm_strip_overwrite_f32': [ctypes.POINTER(_CStripPlan), _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
     'dgnn_spmm_plan_overwrite_f32': [ctypes.POINTER(_CPlan), _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _i32, _f32, _p],
 }
 for _name, _args in _SIGNATURES.items():
     getattr(_lib, _name).argtypes = _args
     getattr(_lib, _name).restype = ctypes.c_int
 _lib.dgnn_last_error.restype = ctypes.c_char_p
-_ABI = 270                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
+_ABI = 280                                # struct layouts and entry points of include/dgnn_spmm.h this stub was written for
 if _lib.dgnn_version() != _ABI:
     raise RuntimeError(f'spmm_cpp: {os.path.normpath(_LIB_PATH)} is version {_lib.dgnn_version()}, this stub needs {_ABI}: '
                        'rebuild it (python -c "import __graft_entry__ as g; g.build(force=True)")')
@@ -405,14 +406,17 @@ class SegPlan:
     block's device; the result is deterministic for a given block, stage count and piece length.
     """
 
-    def __init__(self, A, nstage=1, piece_len=None, hot_rows=0, row_bucket=None):
-        """``hot_rows`` = 256 or 512: a hot-tile plan (struct dgnn_plan, hot_* fields) -- per stage the hot_rows
+    def __init__(self, A, nstage=1, piece_len=None, hot_rows=0, row_bucket=None, skip_rows=None):
+        """``skip_rows`` (bool [n]): rows another call writes (the rows of row-strip tiles, all empty in this block):
+        they are not listed as empty runs, so a product that overwrites C leaves them alone.
+        ``hot_rows`` = 256 or 512: a hot-tile plan (struct dgnn_plan, hot_* fields) -- per stage the hot_rows
         most referenced columns of the column block are served from LDS; the plan then carries its own entry
         arrays ``col`` / ``val`` (hot entries of every run first, column replaced by the tile slot)."""
         dev = A.device
         rp = A.rowptr.long()
         n, nnz = A.n, A.nnz
         self.n = n
+        self.row_bucket = int(row_bucket or 0)
         self.hot_rows = int(hot_rows) if nnz else 0
         if self.hot_rows not in (0, 256, 512):
             raise ValueError('hot_rows must be 0, 256 or 512')
@@ -425,10 +429,17 @@ class SegPlan:
         cbw = max(1, -(-A.m // nstage))
         self.nstage, self.piece_len = nstage, piece_len
         i64 = dict(dtype=torch.long, device=dev)
+        covers = 1 if nnz else 0
         if nnz == 0:
             self.seg = torch.zeros(0, 4, dtype=torch.int32, device=dev)
+            if skip_rows is not None:                             # nothing to multiply, but the rows that are ours get their zeros
+                mine = torch.nonzero(~skip_rows).flatten()
+                z = torch.zeros_like(mine)
+                self.seg = torch.stack([mine, z, z, z - 1], dim=1).int().contiguous()
+                covers = 1
             self.cut = torch.zeros(0, 4, dtype=torch.int32, device=dev)
             self.stage_seg_off = torch.zeros(nstage + 1, dtype=torch.long)
+            self.stage_seg_off[1:] = self.seg.size(0)
             self.stage_cut_off = torch.zeros(nstage + 1, dtype=torch.long)
             self.npartial = 0
         else:
@@ -481,6 +492,10 @@ class SegPlan:
             # then stores every row and a product that overwrites C needs no zero fill (covers_rows)
             has0 = torch.zeros(n, dtype=torch.bool, device=dev)
             has0[run_row[run_cb == 0]] = True
+            if skip_rows is not None:
+                if bool((skip_rows & (rp[1:] > rp[:-1])).any()):
+                    raise ValueError('SegPlan: skip_rows must be empty rows of this block')
+                has0 |= skip_rows
             miss = torch.nonzero(~has0).flatten()
             if miss.numel():
                 at = rp[miss]
@@ -513,7 +528,7 @@ class SegPlan:
         self.nseg = self.seg.size(0)
         self.ncut = self.cut.size(0)
         self.c = _CPlan(nstage, self.seg.data_ptr(), self.stage_seg_off.data_ptr(), self.cut.data_ptr(),
-                        self.stage_cut_off.data_ptr(), self.npartial, int(piece_len), 1 if nnz else 0)
+                        self.stage_cut_off.data_ptr(), self.npartial, int(piece_len), covers)
         if self.hot_rows:
             self.c.hot_rows, self.c.hot_cols, self.c.seg_hot = self.hot_rows, self.hot_cols.data_ptr(), self.seg_hot.data_ptr()
         self._partial = {}
@@ -614,7 +629,12 @@ def _plan_for(A, F):
             hp = A.__dict__.setdefault('_strip_hybrid', {})
             rest_plan = _plan_for_sparse(S.rest, F)
             if id(rest_plan) not in hp:
-                hp[id(rest_plan)] = StripHybridPlan(S, rest_plan)
+                fresh = None
+                if type(rest_plan) is SegPlan and not rest_plan.hot_rows and os.environ.get('DGNN_STRIP_FRESH', '1') == '1':
+                    # the same runs, cut the same way, without the empty runs of the tiles' rows
+                    fresh = SegPlan(S.rest, rest_plan.nstage, rest_plan.piece_len, row_bucket=rest_plan.row_bucket,
+                                    skip_rows=S.strip_rows())
+                hp[id(rest_plan)] = StripHybridPlan(S, rest_plan, fresh)
             return hp[id(rest_plan)]
         D = _dense_for(A)
         if D is not None:
@@ -740,6 +760,10 @@ def spmm_plan(A, B, C, alpha=1.0, beta=1.0, plan=None, overwrite=False):
     if isinstance(plan, StripHybridPlan):                # the rest first (it owns beta / overwrite and lists every row), then the strips
         if float(alpha) != 1.0:
             raise RuntimeError('spmm_plan: row-strip plans multiply with alpha == 1 only')
+        if overwrite and plan.rest_fresh is not None:     # every row written once: the rest's rows by its plan, the tiles' by the strips
+            spmm_plan(plan.strip.rest, B, C, alpha, beta, plan=plan.rest_fresh, overwrite=True)
+            spmm_strip(plan.strip, B, C, fresh=True)
+            return
         spmm_plan(plan.strip.rest, B, C, alpha, beta, plan=plan.rest_plan, overwrite=overwrite)
         spmm_strip(plan.strip, B, C)
         return
@@ -1364,8 +1388,10 @@ class StripHybridPlan:
     """A block as row strips + the rest: ``rest_plan`` (a plan of ``strip.rest``) runs first, with the call's beta /
     overwrite (it lists every row); ``dgnn_spmm_strip_f32`` then adds the strip tiles. A row is whole in one of the two."""
 
-    def __init__(self, strip, rest_plan):
-        self.strip, self.rest_plan = strip, rest_plan
+    def __init__(self, strip, rest_plan, rest_fresh=None):
+        """``rest_fresh``: a SegPlan of the rest that skips the tiles' rows, cut like ``rest_plan`` -- with it a product that
+        overwrites C writes every row once (dgnn_spmm_strip_overwrite_f32) instead of zero-filling the tiles' rows first."""
+        self.strip, self.rest_plan, self.rest_fresh = strip, rest_plan, rest_fresh
 
     def uncut_rows(self):
         """Rows whose result is one strict chain in ascending column order."""
@@ -1374,8 +1400,9 @@ class StripHybridPlan:
     strict_rows = uncut_rows
 
 
-def spmm_strip(S, B, C, alpha=1.0):
-    """C += (strip tiles of S) @ B[:, :F]; B a padded feature block (pad_rows); alpha must be 1."""
+def spmm_strip(S, B, C, alpha=1.0, fresh=False):
+    """C += (strip tiles of S) @ B[:, :F]; B a padded feature block (pad_rows); alpha must be 1.
+    ``fresh``: C[rows of the tiles] = ... instead, written without being read; other rows untouched."""
     bptr, ldb = _dense(B, 'B')
     cptr, ldc = _dense(C, 'C')
     F = C.size(1)
@@ -1383,10 +1410,10 @@ def spmm_strip(S, B, C, alpha=1.0):
     P = S.partial(ldb, dev)
     args = (ctypes.byref(S.c), S.rest.n, S.rest.m, bptr, ldb, cptr, ldc, P.data_ptr(), ldb, F, float(alpha))
     if torch.cuda.current_device() == dev.index:
-        rc = _lib.dgnn_spmm_strip_f32(*args, _stream(C))
+        rc = (_lib.dgnn_spmm_strip_overwrite_f32 if fresh else _lib.dgnn_spmm_strip_f32)(*args, _stream(C))
     else:
         with torch.cuda.device(dev):
-            rc = _lib.dgnn_spmm_strip_f32(*args, _stream(C))
+            rc = (_lib.dgnn_spmm_strip_overwrite_f32 if fresh else _lib.dgnn_spmm_strip_f32)(*args, _stream(C))
     _check(rc, 'spmm_strip')
 
 

@@ -118,7 +118,9 @@ int dgnn_gather_rows_f32(const float* src, int64_t lds, int32_t nsrc, const int3
  *                  run is partial row pbase + p * stride (stride 1 here: 0; row bundles: rows_per_bundle)
  *   stage_cut_off  HOST, int64[nstage + 1]
  *   npartial       rows the `partial` buffer must hold (sum of pieces over all cut runs)
- *   covers_rows    1 if the FIRST stage lists every row of the block -- rows with nothing in the first
+ *   covers_rows    1 if the FIRST stage lists every row the caller wants written (every row of the block; or every row
+ *                  but those another call owns: spmm_cpp.SegPlan(skip_rows=...) beside dgnn_spmm_strip_overwrite_f32)
+ *                  -- rows with nothing in the first
  *                  column block as empty runs (k0 == k1, out = -1) -- so that a product which overwrites C
  *                  (beta = 0, dgnn_spmm_plan_overwrite_f32) needs no zero fill: every row is stored by the
  *                  first stage kernel or by its merge. 0: such a product zero-fills C first.
@@ -323,6 +325,17 @@ typedef struct dgnn_strip_plan {
   int64_t npartial;
 } dgnn_strip_plan;
 int dgnn_spmm_strip_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
+                        int32_t F, float alpha, void* stream);
+/*
+ * The same product for a C that holds nothing yet:  C[rows of the plan's tiles] = A_strip * B -- those rows are written
+ * without being read (the tiles' rows are whole in the plan, so nothing else contributes to them); every other row of C is
+ * left alone. The caller's plan for the remaining rows must then not list the tiles' rows (spmm_cpp.SegPlan(skip_rows=...)):
+ * together the two calls write every row exactly once, where plan-of-the-rest (overwrite) + dgnn_spmm_strip_f32 write the
+ * tiles' rows twice and read them once. Same bits (a chain that starts from +0.0 either way). Replaces z_loc =
+ * torch.zeros(...) (gcn.py:18) plus the first stage for the rows of the tiles.
+ */
+int dgnn_spmm_strip_overwrite_f32(const dgnn_strip_plan* plan, int32_t n, int32_t m,
                         const float* B, int64_t ldb, float* C, int64_t ldc, float* partial, int64_t ldp,
                         int32_t F, float alpha, void* stream);
 

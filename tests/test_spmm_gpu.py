@@ -974,8 +974,45 @@ def test_row_strips_plus_rest_match_the_oracle(n, m, nnz, hubs, F, max_ratio, pi
         over = torch.full((n, F), float('nan'), device=dev)
         spmm_cpp.spmm_plan(blk, Bp, over, 1.0, 1.0, plan, overwrite=True)
         assert torch.equal(over, Cg)
+    # Every row written once (dgnn_spmm_strip_overwrite_f32 + a plan of the rest that skips the tiles' rows): a NaN-filled C,
+    # neither read nor zero-filled, ends up with the bits of "zero-fill, rest, then add the strips" -- signs of zeros included
+    base = torch.zeros(n, F, device=dev)
+    spmm_cpp.spmm_plan(blk, Bp, base, 1.0, 0.0, plan)
+    fresh = spmm_cpp.SegPlan(S.rest, 2, skip_rows=S.strip_rows())
+    assert fresh.nseg == (plan.rest_plan.nseg if S.rest.nnz else n) - int(in_strips.sum()) and fresh.ncut == plan.rest_plan.ncut
+    once = spmm_cpp.StripHybridPlan(S, plan.rest_plan, fresh)
+    over = torch.full((n, F), float('nan'), device=dev)
+    spmm_cpp.spmm_plan(blk, Bp, over, 1.0, 1.0, once, overwrite=True)
+    assert torch.equal(over.view(torch.int32), base.view(torch.int32))
+    if S.rest.nnz:
+        with pytest.raises(ValueError, match='skip_rows'):
+            spmm_cpp.SegPlan(S.rest, 2, skip_rows=~S.strip_rows())      # rows that hold entries cannot be skipped
     with pytest.raises(RuntimeError, match='alpha'):
         spmm_cpp.spmm_plan(blk, Bp, Cg, 0.5, 1.0, plan)
+
+
+def test_row_strips_alone_write_a_block_whose_tiles_are_all_selected():
+    """Every tile selected: nothing is left for the plan of the rest but the zeros of rows outside the tiles -- there are
+    none here -- and the overwriting product is the strip call alone plus an empty plan."""
+    import spmm_cpp
+    from oracle import ref_cpu
+    rng = np.random.default_rng(5)
+    n, m, F = 512, 300, 200
+    row, col, val = _rand_csr(rng, n, m, 40000, hub_rows=0)
+    B = rng.standard_normal((m, F), dtype=np.float32)
+    dev = torch.device('cuda:0')
+    blk = _gpu_block(row, col, val, n, m)
+    S = spmm_cpp.StripPlan(blk, 1.0, 100000, min_tile_nnz=1)             # (no tile cut: every row one chain)
+    assert S.rest.nnz == 0 and S.share == 1.0 and bool(S.strip_rows().all()) and S.ncut == 0
+    rest_plan = spmm_cpp.SegPlan(S.rest, 1)
+    fresh = spmm_cpp.SegPlan(S.rest, 1, skip_rows=S.strip_rows())
+    assert fresh.nseg == 0
+    Bp = spmm_cpp.pad_rows(torch.from_numpy(B).to(dev))
+    want = ref_cpu.spmm_coo(row, col, val, n, m, B, np.zeros((n, F), dtype=np.float32), 1.0, 0.0)
+    for hp in (spmm_cpp.StripHybridPlan(S, rest_plan), spmm_cpp.StripHybridPlan(S, rest_plan, fresh)):
+        C = torch.full((n, F), float('nan'), device=dev)
+        spmm_cpp.spmm_plan(blk, Bp, C, 1.0, 1.0, hp, overwrite=True)
+        assert np.array_equal(C.cpu().numpy(), want)
 
 
 def test_row_strips_keep_non_finite_values_with_their_neighbours():

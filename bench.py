@@ -14,7 +14,8 @@ to CSR + work plans BEFORE the timed region; inputs are resident in HBM when tim
 Prints ONE JSON line on rank 0. `value` = edges aggregated per second by the whole job: every epoch
 runs 2*L SpMM passes over all nnz(A_hat) entries (L forward + L backward aggregations), so
 value = 2*L*nnz*K / t / 1e9. `roofline` covers every SpMM kernel launch of the epoch (`roofline.per_kernel`
-splits the time kernel by kernel; `dominant_kernel` names the largest: spmm_strip_kernel on the Reddit shape),
+splits the time kernel by kernel and, where strips run, gives each kernel the algorithmic bytes of the calls it serves and
+its own `frac`; `dominant_kernel` names the largest: spmm_strip_kernel on the Reddit shape),
 timed with HIP events on the launch stream inside the library (dgnn_prof_begin / dgnn_prof_end_by_kernel) during
 the timed steps. `cpu_baseline` (N = 1 only) is the CPU oracle (the reference's CPU fallback arithmetic restated in C,
 oracle/spmm_ref.c) over the same SpMMs on the box's host threads, with the reference's fallback itself
@@ -362,6 +363,16 @@ def main():
                           avg_launch_ms=round(by_kernel[k][0] / by_kernel[k][1], 4))
                   for k in spmm_cpp.PROF_KERNELS if by_kernel[k][1]}
     dominant = max((k for k in spmm_kinds if by_kernel[k][1]), key=lambda k: by_kernel[k][0], default=None)
+    if by_kernel['strip'][1] and not (by_kernel['bundle'][1] or by_kernel['dense'][1]):
+        # Strips serve the calls of at least 128 floats (padded), the stage kernel the narrower ones and the few rows the
+        # strips leave: the dominant kernel's own roofline fraction = the algorithmic bytes of ITS calls over ITS time
+        # (slightly generous: those calls' leftover rows run in `stage`, whose figure is correspondingly low).
+        wide = [F for F in widths if spmm_cpp.padded_width(F) >= 128]
+        for k, Fs in (('strip', wide), ('stage', [F for F in widths if F not in wide])):
+            if by_kernel[k][0] > 0:
+                b = sum(algorithmic_bytes(blk._nnz(), s, blk.size(1), F, True) for F in Fs for blk in g.adj_parts)
+                per_kernel[k].update(algorithmic_bytes_per_step=int(b), calls_of_widths=Fs,
+                                     frac=round(b * args.steps / (by_kernel[k][0] / 1e3) / 1e9 / HBM_PEAK_GBS, 5))
     roofline = dict(bound='hbm', kernel='every SpMM launch of the epoch: ' + ' + '.join(f'spmm_{k}_kernel' for k in spmm_kinds if by_kernel[k][1]),
                     dominant_kernel=(f'spmm_{dominant}_kernel' if dominant else None), per_kernel=per_kernel,
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
